@@ -1,0 +1,128 @@
+/*
+ * uvaia_gpu.h -- C ABI of the MI355X (gfx950) nearest-neighbour engine.
+ *
+ * This is the drop-in boundary for uvaia's hot path.  The reference (quadram-institute-bioscience/uvaia,
+ * paths below are under /root/reference) has no plugin/FFI layer: the seam is the three OpenMP loops of
+ * src/nearest.c:293-306 (and src/ball.c:248-251) plus the serial per-batch bookkeeping around them.  A
+ * maintainer replaces those loops by calls to this library and keeps everything else (CLI, FASTA streaming,
+ * heap_t/query_t host structures, writers).  See INTEGRATION.md for the patch.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative UVAIA_GPU_E* code and never
+ *     calls exit(); uvaia_gpu_last_error() gives the message (the reference's biomcmc_error() = message + exit,
+ *     src/nearest.c:208,277: the caller turns a code into that behaviour).
+ *   - sequences are nchar upper-case bytes (what readfasta_next() src/fastaseq.c:422-474 and upper_kseq()
+ *     src/utils.c:22 produce).  Alphabet: ACGT, IUPAC partial codes MRWSYKVHDB, and the invalid set
+ *     N X - ? O . (src/utils.c:263).  Any other byte is refused with UVAIA_GPU_EALPHABET (its treatment by the
+ *     absent biomcmc kernel is not pinned by anything in the reference).
+ *   - a "batch" is one pool of the reference (src/nearest.c:249-251): the consensus pre-score of every sequence
+ *     in it is truncated at the largest per-query tolerance at batch start (src/nearest.c:290-291,431-432), so
+ *     batch boundaries are part of the semantics and are chosen by the caller, exactly as --pool is.
+ *   - references are identified by a 64-bit ordinal supplied by the caller; names stay on the host
+ *     (the reference strdup()s names into the heaps, src/min_heap.c:101,112).
+ *   - one context = one GPU = one host thread at a time.
+ */
+#ifndef UVAIA_GPU_H
+#define UVAIA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVAIA_GPU_NSCORE 6          /* q_item.score[6], src/min_heap.h:14-18 */
+
+enum {
+  UVAIA_GPU_OK         =  0,
+  UVAIA_GPU_EINVAL     = -1,   /* bad argument */
+  UVAIA_GPU_ENODEV     = -2,   /* no usable gfx950 device / HIP runtime error at start-up */
+  UVAIA_GPU_ENOMEM     = -3,   /* device or host allocation failed */
+  UVAIA_GPU_EHIP       = -4,   /* HIP runtime error (message in last_error) */
+  UVAIA_GPU_EALPHABET  = -5,   /* a sequence holds a byte outside the supported alphabet */
+  UVAIA_GPU_ESTATE     = -6    /* call sequence error (e.g. push larger than max_pool) */
+};
+
+typedef struct uvaia_gpu_ctx uvaia_gpu_ctx;
+
+/* The prepared query set: the fields of struct query_struct (src/fastaseq.h:41-48) the hot path reads, after
+ * create_query_indices()/reorder_query_structure() (src/fastaseq.c:732-795).  consensus[i] is 'N' where no query
+ * is usable, '#' where queries disagree, else the shared character (src/fastaseq.c:742-756). */
+typedef struct {
+  int n_query;                 /* query->aln->ntax */
+  int nchar;                   /* query->aln->nchar */
+  const char *const *seq;      /* query->aln->character->string[i], nchar bytes each, upper-case */
+  const char *consensus;       /* query->consensus, nchar bytes */
+  const size_t *idx_c, *idx_m, *idx;   /* increasing site indices, as create_query_indices() builds them */
+  int n_idx_c, n_idx_m, n_idx;
+  size_t trim;                 /* query->trim */
+  int acgt;                    /* query->acgt (--acgt) */
+} uvaia_gpu_query;
+
+/* Replaces new_queue() (src/nearest.c:367-390): per-query heaps of max(2,heap_size) slots (src/min_heap.c:58) with
+ * max_incompatible = nchar (src/nearest.c:375,387), plus device buffers for batches of up to max_pool references.
+ * device: HIP device index (-1 = current). */
+int uvaia_gpu_open (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool);
+void uvaia_gpu_close (uvaia_gpu_ctx *ctx);
+const char *uvaia_gpu_last_error (const uvaia_gpu_ctx *ctx);   /* ctx may be NULL: error of the last failed open */
+
+/* Replaces one turn of the batch loop, src/nearest.c:288-306: snapshot of max_incompatible, the consensus pre-score
+ * (queue_distance_to_consensus, :428-433), the per-query gate + heap update over the batch in order
+ * (queue_update_min_heaps{,_full,_acgt}, :435-510) and the OR over is_best (:303-306).
+ *   seq[i]     n_ref sequences of nchar bytes, in stream order (cq->seq[c]); entries must be non-NULL
+ *   non_n[i]   quick_count_sequence_non_N() of each (cq->non_n[c], src/nearest.c:263); NULL = count on the device
+ *   ordinal0   ordinal of seq[0]; seq[i] gets ordinal0+i
+ *   entered[i] out, 1 if the sequence entered the heap of any query during this batch (cq->is_best[n_query*c],
+ *              src/nearest.c:310: such sequences are written to the .aln dump by the caller) */
+int uvaia_gpu_push (uvaia_gpu_ctx *ctx, const char *const *seq, const int *non_n, int n_ref, int64_t ordinal0,
+                    uint8_t *entered);
+
+/* Reads the heaps back.  All arrays are caller-allocated:
+ *   n_items[q]                      heap[q]->n
+ *   max_incompatible[q]             heap[q]->max_incompatible
+ *   scores[(q*(slots+1)+s)*6 + i]   heap[q]->seq[s].score[i], s = 1..n in the reference's binary-heap layout
+ *   ordinals[q*(slots+1)+s]         ordinal of heap[q]->seq[s]
+ * with slots = uvaia_gpu_heap_slots().  Slot 0 is unused, as in src/min_heap.c.  The caller then runs
+ * heap_finalise_heap_qsort() (src/min_heap.c:149-158) on its own heap_t copies. */
+int uvaia_gpu_drain (uvaia_gpu_ctx *ctx, int *n_items, int *max_incompatible, int *scores, int64_t *ordinals);
+int uvaia_gpu_heap_slots (const uvaia_gpu_ctx *ctx);      /* max(2,heap_size) */
+int uvaia_gpu_n_query (const uvaia_gpu_ctx *ctx);
+/* Back to the state right after uvaia_gpu_open() (heaps empty); a resident database is kept. */
+int uvaia_gpu_reset (uvaia_gpu_ctx *ctx);
+
+/* ---- HBM-resident database (the measured configuration: references packed once, scanned many times) ----
+ * Sequences are packed into bit-planes and appended to a device-resident database; they must already have passed
+ * the caller's filters (src/nearest.c:255-278).  non_n as in uvaia_gpu_push (NULL = count on the device). */
+int uvaia_gpu_db_reserve (uvaia_gpu_ctx *ctx, size_t n_ref_capacity);
+int uvaia_gpu_db_append (uvaia_gpu_ctx *ctx, const char *const *seq, const int *non_n, int n_ref);
+/* same, from one host block of n_ref rows of `pitch` bytes (pitch >= nchar) */
+int uvaia_gpu_db_append_block (uvaia_gpu_ctx *ctx, const char *rows, size_t pitch, const int *non_n, int n_ref);
+size_t uvaia_gpu_db_size (const uvaia_gpu_ctx *ctx);
+/* Scans the resident database in batches of `pool` references (ordinals = position in the database + ordinal0),
+ * i.e. the whole while-loop of src/nearest.c:249-330 for one reference file.  entered (may be NULL): db_size bytes.
+ * Asynchronous with respect to the host unless entered != NULL; uvaia_gpu_sync() waits. */
+int uvaia_gpu_search_resident (uvaia_gpu_ctx *ctx, size_t pool, int64_t ordinal0, uint8_t *entered);
+int uvaia_gpu_sync (uvaia_gpu_ctx *ctx);
+
+/* ---- radius search: replaces the loop of src/ball.c:248-251 (seq_ball_against_query_structure,
+ * src/fastaseq.c:660-696) for one batch.  radius = cq->dist + 1.  mindist[i] receives what the reference leaves in
+ * cq->mindist[c]; the caller keeps sequence i iff mindist[i] <= radius-1 (src/ball.c:255). */
+int uvaia_gpu_ball (uvaia_gpu_ctx *ctx, const char *const *seq, int n_ref, int radius, int *mindist);
+
+/* ---- introspection used by tests and bench.py ---- */
+/* untruncated pair scores of the last batch: out[(i*n_query+q)*6 + s] = the score[] vector src/nearest.c:499-501
+ * (or :464-469 with --acgt) assembles for (reference i of the batch, query q) when nothing is truncated. */
+int uvaia_gpu_last_batch_scores (uvaia_gpu_ctx *ctx, int *out, int n_ref);
+/* device time (ms) and launch count of the dominant kernel (the pair scan), measured with HIP events on the
+ * context's stream since the last call with reset != 0; bytes = algorithmic bytes those launches covered. */
+int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, double *algorithmic_bytes, int reset);
+/* tuning knob: queries held per pass of the scan kernel (8, 16 or 32); 0 = default */
+int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
+/* bytes per packed reference in HBM */
+size_t uvaia_gpu_packed_bytes_per_ref (const uvaia_gpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle, bit for bit.
+
+Everything here needs a real MI355X: `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+import fixtures as F
+import oracle_lib as O
+from uvaia_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(n, p="r"):
+    return ["%s%d" % (p, i) for i in range(n)]
+
+
+def _gpu_search(q, refs, pool, nbest, non_n=None):
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool) as eng:
+        entered = []
+        for a in range(0, len(refs), pool):
+            nn = None if non_n is None else non_n[a:a + pool]
+            entered.append(eng.push(refs[a:a + pool], non_n=nn))
+        n, T, sc, od = eng.drain()
+    return capi.finalise_heaps(n, sc, od), list(T), np.concatenate(entered) if entered else np.zeros(0, np.uint8)
+
+
+def _assert_same_search(q, refs, pool, nbest, **kw):
+    gold = O.search(q, refs, _names(len(refs)), pool=pool, nbest=nbest, ambig_r=1.0)   # ambig_r=1: no reference is filtered
+    rows, T, entered = _gpu_search(q, refs, pool, nbest, **kw)
+    for iq in range(q.ntax):
+        want = [(tuple(s), o) for o, _, s in gold.rows[iq]]
+        assert rows[iq] == want, "query %d (%s)" % (iq, q.names[iq])
+    assert T == gold.final_T
+    assert list(np.nonzero(entered)[0]) == list(gold.saved)
+
+
+@pytest.fixture(scope="module")
+def synth():
+    refs, root, cols = F.synth_alignment(700, 2500, seed=11)
+    qs, _, _ = F.synth_alignment(40, 2500, seed=12, root=root, poly_cols=cols)
+    return refs, qs
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("trim", [0, 230])
+def test_allpairs_counts_synthetic(synth, acgt, trim):
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"), trim=trim, acgt=acgt)
+    want = q.allpairs(refs[:300])
+    with capi.Engine.from_query(q, nbest=5, max_pool=512) as eng:
+        eng.push(refs[:300])
+        got = eng.last_batch_scores(300)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_allpairs_counts_bundled(bundled_db, acgt):
+    """16 queries x 512 references of the reference's own alignment, untruncated counts, trim 0 and 230."""
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:16]
+    for trim in (0, 230):
+        q = O.Query([by[n] for n in qn], qn, trim=trim, acgt=acgt)
+        want = q.allpairs(seqs[:512])
+        with capi.Engine.from_query(q, nbest=5, max_pool=512) as eng:
+            eng.push(seqs[:512])
+            got = eng.last_batch_scores(512)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("pool,nbest", [(64, 5), (100, 1), (700, 20), (33, 100)])
+def test_search_matches_oracle_synthetic(synth, acgt, pool, nbest):
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+    _assert_same_search(q, refs, pool, nbest)
+
+
+def test_search_host_supplied_non_n(synth):
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"))
+    non_n = np.array([O.lib().orc_count_non_N(r, len(r)) for r in refs], dtype=np.int32)
+    _assert_same_search(q, refs, 128, 10, non_n=non_n)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_config1_bundled_db(bundled_db, acgt):
+    """BASELINE config 1: bundled alignment as the database, the first 10 sample names as queries, --nbest 5, pool 64."""
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:10]
+    q = O.Query([by[n] for n in qn], qn, acgt=acgt)
+    refs = seqs[:3000]
+    gold = O.search(q, refs, names[:3000], pool=64, nbest=5)
+    # the oracle drops low-quality references before they occupy a pool slot (src/nearest.c:263-270): feed the GPU the survivors
+    keep = [i for i, r in enumerate(refs) if O.lib().orc_count_non_N(r, len(r)) >= int(len(r) * 0.5)]
+    assert len(keep) == len(refs) - gold.n_lowqual
+    kept = [refs[i] for i in keep]
+    with capi.Engine.from_query(q, nbest=5, max_pool=64) as eng:
+        ent = []
+        for a in range(0, len(kept), 64):
+            ent.append(eng.push(kept[a:a + 64], ordinal0=a))
+        n, T, sc, od = eng.drain()
+    rows = capi.finalise_heaps(n, sc, od)
+    for iq in range(q.ntax):
+        want = [(tuple(s), keep.index(o)) for o, _, s in gold.rows[iq]]
+        assert rows[iq] == want
+    assert list(T) == gold.final_T
+    ent = np.concatenate(ent)
+    assert [keep[i] for i in np.nonzero(ent)[0]] == list(gold.saved)
+
+
+def test_resident_equals_streaming(synth):
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"))
+    for pool in (64, 100, 333):
+        rows_s, T_s, ent_s = _gpu_search(q, refs, pool, 7)
+        with capi.Engine.from_query(q, nbest=7, max_pool=512) as eng:
+            eng.db_reserve(len(refs))
+            eng.db_append(refs[:130])          # appends need not be tile aligned
+            eng.db_append(refs[130:])
+            ent = eng.search_resident(pool)
+            n, T, sc, od = eng.drain()
+            assert capi.finalise_heaps(n, sc, od) == rows_s
+            assert list(T) == T_s
+            assert np.array_equal(ent, ent_s)
+            eng.reset()                         # a second pass over the resident database gives the same answer
+            eng.search_resident(pool, want_entered=False)
+            n2, T2, sc2, od2 = eng.drain()
+            assert capi.finalise_heaps(n2, sc2, od2) == rows_s
+
+
+def test_query_tile_sizes_agree(synth):
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"))
+    want = q.allpairs(refs[:200])
+    for qt in (8, 16, 32):
+        with capi.Engine.from_query(q, nbest=5, max_pool=256) as eng:
+            eng.set_query_tile(qt)
+            eng.push(refs[:200])
+            assert np.array_equal(eng.last_batch_scores(200), want)
+
+
+def test_refuses_unknown_bytes(synth):
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"))
+    bad = bytearray(refs[0]); bad[100] = ord("U")
+    with capi.Engine.from_query(q, nbest=5, max_pool=64) as eng:
+        with pytest.raises(capi.GpuError) as ei:
+            eng.push([bytes(bad)])
+        assert ei.value.code == -5
+        eng.push(refs[:10])          # the context stays usable
+
+
+def test_truncated_consensus_prescore_is_reproduced():
+    """Cross-query coupling through cq->max_incompatible (src/nearest.c:290-291,431-432): a reference whose
+    consensus pre-score was cut at the batch-start snapshot can still pass the gate of a query whose tolerance rose
+    above the snapshot inside the batch; the truncated counters then enter the heap.  Built so that it happens."""
+    L = 400
+    A, C_, G, T = b"A", b"C", b"G", b"T"
+    base = bytearray(A * L)
+    qseq = bytes(base)                       # one clean query -> every column is idx_c
+    q = O.Query([qseq], ["q0"])
+    assert len(q.idx_c) == L
+
+    def ref_with(mism_sites, n_sites=()):
+        s = bytearray(base)
+        for i in mism_sites: s[i] = ord("C")
+        for i in n_sites: s[i] = ord("N")
+        return bytes(s)
+
+    # heap size 2, pool 2.  Batch 1 fills the heap with
+    #   A: 10 mismatches, full length  -> 390 matches, m = 10
+    #   B: 1 mismatch, 200 N's         -> 199 matches, m = 1     (root = worst = B, so T = 2)
+    b1 = [ref_with(range(1, 11)), ref_with([20], n_sites=range(200, 400))]
+    # Batch 2 starts with snapshot = max T = 2.
+    #   r2: perfect full-length sequence: enters, evicts B; the new root is A (m = 10) -> T = 11 > snapshot.
+    #   r3: 3 mismatches at sites 390, 395, 399: its pre-score was cut at the 2nd mismatch (site 395), so cq->res holds
+    #       matches = 394, valid = 396; the gate (2 < 11) lets it through and the TRUNCATED scores 394/396 enter the heap
+    #       (the untruncated ones would be 397/400).
+    b2 = [ref_with([]), ref_with([390, 395, 399])]
+    refs = b1 + b2
+    gold = O.search(q, refs, _names(4), pool=2, nbest=2, ambig_r=1.0)
+    got_scores = sorted(tuple(s) for _, _, s in gold.rows[0])
+    assert (394, 394, 394, 396, 0, 400) in got_scores, got_scores      # the oracle shows the reference's quirk
+    rows, Tq, ent = _gpu_search(q, refs, 2, 2)
+    assert rows[0] == [(tuple(s), o) for o, _, s in gold.rows[0]]
+    assert Tq == gold.final_T
+    # with one big batch nothing is truncated in a way that matters and the true scores enter
+    gold1 = O.search(q, refs, _names(4), pool=4, nbest=2, ambig_r=1.0)
+    rows1, T1, _ = _gpu_search(q, refs, 4, 2)
+    assert rows1[0] == [(tuple(s), o) for o, _, s in gold1.rows[0]]
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_random_small_many_states(acgt):
+    """Many tiny problems with heavy ties and tiny heaps: exercises heap layout / tie handling / T dynamics."""
+    rng = np.random.default_rng(5)
+    for it in range(12):
+        L = int(rng.integers(40, 200))
+        refs, root, cols = F.synth_alignment(int(rng.integers(5, 150)), L, seed=100 + it, p_snp=0.02, p_amb=0.01)
+        qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=200 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)
+        q = O.Query(qs, _names(len(qs), "q"), acgt=acgt, ambig_q=1.0)
+        if q.ntax < 1:
+            continue
+        _assert_same_search(q, refs, int(rng.integers(1, 40)), int(rng.integers(1, 12)))

@@ -1,0 +1,245 @@
+"""ctypes binding of include/uvaia_gpu.h (the only way Python reaches the engine)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+_LIB = os.path.join(_HERE, "lib", "libuvaia_gpu.so")
+NSCORE = 6
+
+# every symbol include/uvaia_gpu.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "uvaia_gpu_open", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
+    "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
+    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball",
+    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
+]
+
+
+class GpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("uvaia_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Query(C.Structure):
+    _fields_ = [
+        ("n_query", C.c_int), ("nchar", C.c_int),
+        ("seq", C.POINTER(C.c_char_p)), ("consensus", C.c_char_p),
+        ("idx_c", C.POINTER(C.c_size_t)), ("idx_m", C.POINTER(C.c_size_t)), ("idx", C.POINTER(C.c_size_t)),
+        ("n_idx_c", C.c_int), ("n_idx_m", C.c_int), ("n_idx", C.c_int),
+        ("trim", C.c_size_t), ("acgt", C.c_int),
+    ]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc", "uvaia_gpu.hip")
+    hdr = os.path.join(ROOT, "include", "uvaia_gpu.h")
+    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return _LIB
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """Load libuvaia_gpu.so; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise GpuError(-2, "HIP library %s is missing: run __graft_entry__.build() (no CPU fallback exists)" % _LIB)
+    L = C.CDLL(_LIB)
+    vp = C.c_void_p
+    pp = C.POINTER(C.c_char_p)
+    pi = C.POINTER(C.c_int)
+    sig = {
+        "uvaia_gpu_open": (C.c_int, [C.POINTER(vp), C.POINTER(_Query), C.c_int, C.c_int, C.c_size_t]),
+        "uvaia_gpu_close": (None, [vp]),
+        "uvaia_gpu_last_error": (C.c_char_p, [vp]),
+        "uvaia_gpu_push": (C.c_int, [vp, pp, pi, C.c_int, C.c_int64, C.POINTER(C.c_uint8)]),
+        "uvaia_gpu_drain": (C.c_int, [vp, pi, pi, pi, C.POINTER(C.c_int64)]),
+        "uvaia_gpu_heap_slots": (C.c_int, [vp]),
+        "uvaia_gpu_n_query": (C.c_int, [vp]),
+        "uvaia_gpu_reset": (C.c_int, [vp]),
+        "uvaia_gpu_db_reserve": (C.c_int, [vp, C.c_size_t]),
+        "uvaia_gpu_db_append": (C.c_int, [vp, pp, pi, C.c_int]),
+        "uvaia_gpu_db_append_block": (C.c_int, [vp, C.c_void_p, C.c_size_t, pi, C.c_int]),
+        "uvaia_gpu_db_size": (C.c_size_t, [vp]),
+        "uvaia_gpu_search_resident": (C.c_int, [vp, C.c_size_t, C.c_int64, C.POINTER(C.c_uint8)]),
+        "uvaia_gpu_sync": (C.c_int, [vp]),
+        "uvaia_gpu_ball": (C.c_int, [vp, pp, C.c_int, C.c_int, pi]),
+        "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
+        "uvaia_gpu_scan_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]),
+        "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
+        "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _cstrs(strs):
+    arr = (C.c_char_p * len(strs))()
+    for i, s in enumerate(strs):
+        arr[i] = s
+    return arr
+
+
+def _int_ptr(a):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(a, dtype=np.int32)
+    return arr, arr.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Engine:
+    """One GPU context over a prepared query set (fields of struct query_struct, src/fastaseq.h:41-48)."""
+
+    def __init__(self, seqs, consensus, idx_c, idx_m, idx, trim=0, acgt=False, nbest=100, max_pool=4096, device=-1):
+        self.L = load_library()
+        self.nq, self.nchar = len(seqs), len(consensus)
+        self._keep = [_cstrs(seqs), consensus,
+                      (C.c_size_t * len(idx_c))(*[int(x) for x in idx_c]),
+                      (C.c_size_t * len(idx_m))(*[int(x) for x in idx_m]),
+                      (C.c_size_t * len(idx))(*[int(x) for x in idx])]
+        q = _Query(self.nq, self.nchar, self._keep[0], consensus, self._keep[2], self._keep[3], self._keep[4],
+                   len(idx_c), len(idx_m), len(idx), int(trim), int(bool(acgt)))
+        self.ctx = C.c_void_p()
+        rc = self.L.uvaia_gpu_open(C.byref(self.ctx), C.byref(q), int(nbest), int(device), int(max_pool))
+        if rc != 0:
+            msg = self.L.uvaia_gpu_last_error(None)
+            self.ctx = None
+            raise GpuError(rc, msg.decode() if msg else "?")
+        self.slots = self.L.uvaia_gpu_heap_slots(self.ctx)
+        self.ordinal = 0
+
+    @classmethod
+    def from_query(cls, q, **kw):
+        """q: any object with seqs, consensus, idx_c, idx_m, idx, trim, acgt."""
+        return cls(q.seqs, q.consensus, q.idx_c, q.idx_m, q.idx, trim=q.trim, acgt=q.acgt, **kw)
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.L.uvaia_gpu_last_error(self.ctx)
+            raise GpuError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.uvaia_gpu_close(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def push(self, refs, non_n=None, ordinal0=None):
+        """One batch (= one pool of the reference) in stream order; returns the 'entered any heap' flags."""
+        n = len(refs)
+        if ordinal0 is None:
+            ordinal0 = self.ordinal
+        self.ordinal = ordinal0 + n
+        entered = np.zeros(n, dtype=np.uint8)
+        if n == 0:
+            return entered
+        _k, nn = _int_ptr(non_n)
+        self._chk(self.L.uvaia_gpu_push(self.ctx, _cstrs(refs), nn, n, ordinal0, entered.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return entered
+
+    def last_batch_scores(self, n):
+        out = np.zeros((n, self.nq, NSCORE), dtype=np.int32)
+        self._chk(self.L.uvaia_gpu_last_batch_scores(self.ctx, out.ctypes.data_as(C.POINTER(C.c_int)), n))
+        return out
+
+    def drain(self):
+        """(n_items[q], max_incompatible[q], scores[q, slot, 6], ordinals[q, slot]) in heap layout (slot 0 unused)."""
+        n = np.zeros(self.nq, dtype=np.int32)
+        T = np.zeros(self.nq, dtype=np.int32)
+        sc = np.zeros((self.nq, self.slots + 1, NSCORE), dtype=np.int32)
+        od = np.zeros((self.nq, self.slots + 1), dtype=np.int64)
+        pi = C.POINTER(C.c_int)
+        self._chk(self.L.uvaia_gpu_drain(self.ctx, n.ctypes.data_as(pi), T.ctypes.data_as(pi), sc.ctypes.data_as(pi),
+                                         od.ctypes.data_as(C.POINTER(C.c_int64))))
+        return n, T, sc, od
+
+    def reset(self):
+        self.ordinal = 0
+        self._chk(self.L.uvaia_gpu_reset(self.ctx))
+
+    def db_reserve(self, n):
+        self._chk(self.L.uvaia_gpu_db_reserve(self.ctx, int(n)))
+
+    def db_append(self, refs, non_n=None):
+        _k, nn = _int_ptr(non_n)
+        self._chk(self.L.uvaia_gpu_db_append(self.ctx, _cstrs(refs), nn, len(refs)))
+
+    def db_append_block(self, block, non_n=None):
+        """block: uint8 array [n, pitch] (pitch >= nchar)."""
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        _k, nn = _int_ptr(non_n)
+        self._chk(self.L.uvaia_gpu_db_append_block(self.ctx, block.ctypes.data, block.shape[1], nn, block.shape[0]))
+
+    def db_size(self):
+        return self.L.uvaia_gpu_db_size(self.ctx)
+
+    def search_resident(self, pool, ordinal0=0, want_entered=True):
+        ent, p = None, None
+        if want_entered:
+            ent = np.zeros(self.db_size(), dtype=np.uint8)
+            p = ent.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._chk(self.L.uvaia_gpu_search_resident(self.ctx, int(pool), int(ordinal0), p))
+        return ent
+
+    def sync(self):
+        self._chk(self.L.uvaia_gpu_sync(self.ctx))
+
+    def scan_stats(self, reset=False):
+        ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
+        self._chk(self.L.uvaia_gpu_scan_stats(self.ctx, C.byref(ms), C.byref(n), C.byref(b), int(reset)))
+        return ms.value, n.value, b.value
+
+    def set_query_tile(self, qt):
+        self._chk(self.L.uvaia_gpu_set_query_tile(self.ctx, int(qt)))
+
+    def packed_bytes_per_ref(self):
+        return self.L.uvaia_gpu_packed_bytes_per_ref(self.ctx)
+
+    def ball(self, refs, radius):
+        md = np.zeros(len(refs), dtype=np.int32)
+        self._chk(self.L.uvaia_gpu_ball(self.ctx, _cstrs(refs), len(refs), int(radius), md.ctypes.data_as(C.POINTER(C.c_int))))
+        return md
+
+
+def finalise_heaps(n, scores, ordinals):
+    """heap_finalise_heap_qsort (src/min_heap.c:149-158) on drained heaps: per query the rows best-first.
+
+    The reference moves slots [1..n] to [0..n-1] by swapping slot 0 with slot n and then calls glibc qsort, which is
+    a stable merge sort; a stable sort over that exact starting order gives the same table on any libc."""
+    out = []
+    for q in range(len(n)):
+        k = int(n[q])
+        order = ([k] + list(range(1, k))) if k else []          # slot n moved to position 0
+        rows = [(tuple(int(x) for x in scores[q, s]), int(ordinals[q, s])) for s in order]
+        rows.sort(key=lambda r: tuple(-v for v in r[0]))        # list.sort is stable
+        out.append(rows)
+    return out

@@ -1,0 +1,941 @@
+// uvaia_gpu.hip -- MI355X (gfx950 / CDNA4) engine behind include/uvaia_gpu.h.
+//
+// What it replaces in the reference (paths under /root/reference): the three OpenMP loops of
+// src/nearest.c:293-306 -- consensus pre-score, per-query gate + heap update, is_best OR -- and the scoring
+// kernels they call (src/fastaseq.c:585-596 and the absent biomcmc 4-count kernel, see oracle/uvaia_oracle.h).
+//
+// Design:
+//   * sequences live in HBM as bit-planes, interleaved per tile of 64 references so that one lane owns one
+//     reference: tile[t][w4][plane][lane] is a uint4 holding alignment words 4*w4..4*w4+3 (32 sites per word) of
+//     that plane for reference 64*t+lane.  One wave-wide dwordx4 load = 1 KiB contiguous.
+//   * the scan kernel keeps QT queries' accumulators in VGPRs; query words are wave-uniform and arrive through
+//     scalar loads (SGPR operands of v_bitop3/v_and/v_xor), so the inner loop is pure VALU + v_bcnt with no
+//     LDS traffic and no cross-lane reduction.  No MFMA: this is a popcount scan.
+//   * the order-dependent gate/heap state machine of src/nearest.c:479-510 runs on the device, one wave per
+//     query, over the dense pair counts of a batch, reproducing the reference's heap layout slot for slot.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uvaia_gpu.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------
+#define TT_A 0xF0u   // v_bitop3 truth-table columns: src0, src1, src2
+#define TT_B 0xCCu
+#define TT_C 0xAAu
+#define B3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt) & 0xFFu)
+
+static __device__ __forceinline__ int bcnt_acc(uint32_t x, int acc)
+{ // v_bcnt_u32_b32 d, x, acc : popcount with free accumulate (keeps one VALU op per count and word)
+  int r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+namespace {
+
+constexpr int HEAP_ENTRY = 8;          // 6 scores + 64-bit ordinal (lo, hi)
+constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
+
+thread_local std::string g_open_error;
+
+struct ScanEvt { hipEvent_t a, b; double bytes; };
+
+}  // namespace
+
+struct uvaia_gpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16;
+  size_t trim = 0;
+  size_t max_pool = 0, pool_pad = 0;
+  // query side
+  uint32_t *d_qp = nullptr;      // [nq_pad][W4][4][NQ]
+  uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
+  uint32_t *d_cpm = nullptr;     // consensus restricted to idx_m (radius search)
+  uint32_t *d_qpoly = nullptr;   // queries restricted to idx (radius search), [nq_pad][W4][4][NQ]
+  std::vector<uint32_t> h_qp_poly_src;  // kept to build d_qpoly lazily
+  // heaps / state
+  int *d_heap = nullptr, *d_n = nullptr, *d_T = nullptr, *d_snap = nullptr, *d_err = nullptr;
+  // batch buffers
+  uint4 *d_batch = nullptr;      // packed tiles of the current batch
+  int *d_batch_nonn = nullptr;
+  int4 *d_cnt = nullptr;         // [nq_pad][pool_pad]
+  int4 *d_rt = nullptr, *d_tr = nullptr;   // [pool_pad]
+  uint8_t *d_entered = nullptr;  // [pool_pad] (push) or [db_cap] (resident)
+  size_t entered_cap = 0;
+  uint8_t *d_stage = nullptr;    // device staging for raw characters (PACK_CHUNK rows)
+  uint8_t *h_stage = nullptr;    // pinned host staging
+  size_t pitch = 0;
+  // resident database
+  uint4 *d_db = nullptr;
+  int *d_db_nonn = nullptr;
+  size_t db_cap = 0, db_n = 0;
+  // last batch (introspection)
+  const uint4 *last_tiles = nullptr; const int *last_nonn = nullptr; int last_n = 0, last_rbegin = 0, last_ppad = 0;
+  // stats
+  std::vector<ScanEvt> evts;
+  double scan_ms = 0, scan_bytes = 0; long long scan_launches = 0;
+  bool profile = true;
+  std::string err;
+};
+
+namespace {
+
+int fail(uvaia_gpu_ctx *c, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf; else g_open_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return fail((c), e_ == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// IUPAC code table: 1..15 = nucleotide set (A=1 C=2 G=4 T=8), 0 = invalid site (N X - ? O .), 0xFF = refused
+void fill_code_table(uint8_t *t)
+{
+  memset(t, 0xFF, 256);
+  const char *inv = "NnXx-?Oo.";                      // src/utils.c:263
+  for (const char *p = inv; *p; p++) t[(unsigned char)*p] = 0;
+  static const struct { char c; uint8_t m; } iu[] = {
+    {'A',1},{'C',2},{'G',4},{'T',8},{'M',3},{'R',5},{'W',9},{'S',6},{'Y',10},{'K',12},{'V',7},{'H',11},{'D',13},{'B',14}};
+  for (auto &e : iu) { t[(unsigned char)e.c] = e.m; t[(unsigned char)(e.c + 32)] = e.m; }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// device: packing raw characters into tile-interleaved bit-planes
+// ------------------------------------------------------------------------------------------------------------
+__constant__ uint8_t c_code[256];
+
+// One block per tile of 64 database slots; wave v handles word groups w4 = v, v+4, ...  Slots outside
+// [slot0, slot0+n_ref) are left untouched (the database is zero-initialised), so appends need not be tile-aligned.
+// non_n_out (nullable): valid-site count over the FULL length (src/fastaseq.c:642-648).
+template <int P>
+__global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restrict__ chars, size_t pitch, int nchar,
+                                                         long long slot0, int n_ref, int W4, uint4 *__restrict__ tiles,
+                                                         long long tile_base, int *__restrict__ non_n_out, int *__restrict__ errflag)
+{
+  __shared__ uint8_t lut[256];
+  __shared__ int partial[4][64];
+  lut[threadIdx.x] = c_code[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long tile = tile_base + blockIdx.x;
+  const long long slot = tile * 64 + lane;
+  const long long i = slot - slot0;                  // row in chars
+  const bool active = (i >= 0 && i < n_ref);
+  const uint8_t *row = chars + (active ? (size_t)i * pitch : 0);
+  const bool vec = ((pitch & 15) == 0) && ((((uintptr_t)chars) & 15) == 0);
+  int valid = 0, bad = 0;
+  for (int w4 = wv; w4 < W4; w4 += 4) {
+    uint32_t pl[4][4];                               // [plane][j]
+#pragma unroll
+    for (int p = 0; p < 4; p++) { pl[p][0] = pl[p][1] = pl[p][2] = pl[p][3] = 0; }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int site0 = (w4 * 4 + j) * 32;
+        if (site0 >= nchar) break;
+        uint8_t b[32];
+        if (vec && site0 + 32 <= (int)pitch) {
+          const uint4 *v = reinterpret_cast<const uint4 *>(row + site0);
+          uint4 x0 = v[0], x1 = v[1];
+          memcpy(b, &x0, 16); memcpy(b + 16, &x1, 16);
+        } else {
+          for (int s = 0; s < 32; s++) b[s] = (site0 + s < nchar) ? row[site0 + s] : (uint8_t)'N';
+        }
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+          uint32_t code = (site0 + s < nchar) ? lut[b[s]] : 0u;
+          if (code == 0xFFu) { bad = 1; code = 0; }
+          valid += (code != 0);
+          if (P == 4) {
+            a0 |= (code & 1u) << s; a1 |= ((code >> 1) & 1u) << s; a2 |= ((code >> 2) & 1u) << s; a3 |= ((code >> 3) & 1u) << s;
+          } else {  // 2-bit code + "is ACGT" plane: A=0 C=1 G=2 T=3
+            const uint32_t one = (code != 0) & ((code & (code - 1)) == 0);
+            const uint32_t two = (code == 2) ? 1u : (code == 4) ? 2u : (code == 8) ? 3u : 0u;
+            a0 |= (two & 1u & one) << s; a1 |= ((two >> 1) & one) << s; a2 |= one << s;
+          }
+        }
+        pl[0][j] = a0; pl[1][j] = a1; pl[2][j] = a2; pl[3][j] = a3;
+      }
+      uint4 *dst = tiles + ((size_t)(tile * W4 + w4) * P) * 64 + lane;
+#pragma unroll
+      for (int p = 0; p < P; p++) dst[(size_t)p * 64] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    }
+  }
+  partial[wv][lane] = valid;
+  __syncthreads();
+  if (wv == 0 && active && non_n_out) non_n_out[slot] = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+  if (bad) atomicOr(errflag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: the pair scan (dominant kernel)
+// ------------------------------------------------------------------------------------------------------------
+template <int N> struct QWords { uint32_t v[N]; };
+template <int N> static __device__ __forceinline__ void load_qwords(QWords<N> &d, const uint32_t *__restrict__ p)
+{
+#pragma unroll
+  for (int i = 0; i < N; i++) d.v[i] = p[i];   // wave-uniform address -> s_load_dwordx8/x16
+}
+
+// Default mode: 4 planes (A,C,G,T bits of the IUPAC set).  Per (reference, query) pair and 32-site word:
+//   r0 = #(equal & ACGT)  r1 = #(equal & both valid)  r2 = #(sets intersect)  r3 = #(both valid)
+// (the four counters of the biomcmc kernel, call sites src/nearest.c:491,495).  15 VALU ops per pair-word.
+// query planes per word: A,C,G,T, valid, is-ACGT.
+template <int QT>
+__global__ __launch_bounds__(256) void scan_iupac_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
+                                                          const uint32_t *__restrict__ qp, int4 *__restrict__ out, int ppad)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int trel = blockIdx.y * 4 + wave;
+  if (trel >= n_tiles) return;
+  const int q0 = blockIdx.x * QT;
+  int acc[QT][4];
+#pragma unroll
+  for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0; }
+  const uint4 *t = db + (size_t)(tile_first + trel) * W4 * 4 * 64 + lane;
+  const size_t qstride = (size_t)W4 * 24;
+  const uint32_t *qb = qp + (size_t)q0 * qstride;
+  for (int w4 = 0; w4 < W4; w4++) {
+    const uint4 pA = t[(size_t)(w4 * 4 + 0) * 64], pC = t[(size_t)(w4 * 4 + 1) * 64], pG = t[(size_t)(w4 * 4 + 2) * 64], pT = t[(size_t)(w4 * 4 + 3) * 64];
+    const uint32_t rA[4] = {pA.x, pA.y, pA.z, pA.w}, rC[4] = {pC.x, pC.y, pC.z, pC.w}, rG[4] = {pG.x, pG.y, pG.z, pG.w}, rT[4] = {pT.x, pT.y, pT.z, pT.w};
+    uint32_t rv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rv[j] = rA[j] | rC[j] | rG[j] | rT[j];
+    const uint32_t *s0 = qb + (size_t)w4 * 24;
+    QWords<24> cur, nxt;
+    load_qwords(cur, s0);
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t qA = cur.v[j * 6 + 0], qC = cur.v[j * 6 + 1], qG = cur.v[j * 6 + 2], qT_ = cur.v[j * 6 + 3], qv = cur.v[j * 6 + 4], qa = cur.v[j * 6 + 5];
+        uint32_t d = rA[j] ^ qA;
+        d = B3(rC[j], qC, d, (TT_A ^ TT_B) | TT_C);
+        d = B3(rG[j], qG, d, (TT_A ^ TT_B) | TT_C);
+        const uint32_t nd = B3(rT[j], qT_, d, ~((TT_A ^ TT_B) | TT_C));   // all four planes equal
+        uint32_t x = rA[j] & qA;
+        x = B3(rC[j], qC, x, (TT_A & TT_B) | TT_C);
+        x = B3(rG[j], qG, x, (TT_A & TT_B) | TT_C);
+        x = B3(rT[j], qT_, x, (TT_A & TT_B) | TT_C);                       // sets intersect (implies both valid)
+        acc[q][0] = bcnt_acc(nd & qa, acc[q][0]);
+        acc[q][1] = bcnt_acc(nd & rv[j], acc[q][1]);
+        acc[q][2] = bcnt_acc(x, acc[q][2]);
+        acc[q][3] = bcnt_acc(rv[j] & qv, acc[q][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < QT) cur = nxt;
+    }
+  }
+  const size_t r = (size_t)trel * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+}
+
+// --acgt mode: 3 planes (lo, hi of the 2-bit code, is-ACGT).  Per pair-word:
+//   c0 = #(both ACGT & differ)  c1 = #(both ACGT)  c2 = #(both ACGT & differ) on polymorphic query columns
+// (src/fastaseq.c:585-596; c2 separates score[5] from score[4], src/nearest.c:468-469).  8 VALU ops per pair-word.
+// query planes per word: lo, hi, is-ACGT, is-ACGT restricted to the polymorphic columns (query->idx).
+template <int QT>
+__global__ __launch_bounds__(256) void scan_acgt_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
+                                                         const uint32_t *__restrict__ qp, int4 *__restrict__ out, int ppad)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int trel = blockIdx.y * 4 + wave;
+  if (trel >= n_tiles) return;
+  const int q0 = blockIdx.x * QT;
+  int acc[QT][3];
+#pragma unroll
+  for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = acc[q][2] = 0; }
+  const uint4 *t = db + (size_t)(tile_first + trel) * W4 * 3 * 64 + lane;
+  const size_t qstride = (size_t)W4 * 16;
+  const uint32_t *qb = qp + (size_t)q0 * qstride;
+  for (int w4 = 0; w4 < W4; w4++) {
+    const uint4 pL = t[(size_t)(w4 * 3 + 0) * 64], pH = t[(size_t)(w4 * 3 + 1) * 64], pI = t[(size_t)(w4 * 3 + 2) * 64];
+    const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
+    const uint32_t *s0 = qb + (size_t)w4 * 16;
+    QWords<16> cur, nxt;
+    load_qwords(cur, s0);
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t qL = cur.v[j * 4 + 0], qH = cur.v[j * 4 + 1], qI = cur.v[j * 4 + 2], qIp = cur.v[j * 4 + 3];
+        const uint32_t d = rL[j] ^ qL;
+        const uint32_t y = B3(rH[j], qH, d, (TT_A ^ TT_B) | TT_C);     // codes differ
+        acc[q][0] = bcnt_acc(B3(y, rI[j], qI, TT_A & TT_B & TT_C), acc[q][0]);
+        acc[q][1] = bcnt_acc(rI[j] & qI, acc[q][1]);
+        acc[q][2] = bcnt_acc(B3(y, rI[j], qIp, TT_A & TT_B & TT_C), acc[q][2]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < QT) cur = nxt;
+    }
+  }
+  const size_t r = (size_t)trel * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int4(acc[q][0], acc[q][1], acc[q][2], 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: consensus pre-score with the reference's truncation (queue_distance_to_consensus, src/nearest.c:428-433)
+// ------------------------------------------------------------------------------------------------------------
+// One lane per reference walks the alignment words in increasing site order against the consensus restricted to
+// query->idx_c.  rt = untruncated counters; tr = the counters the reference's early-exit loop would return with
+// maxdist = *snap (it stops right after the site at which the mismatch counter reaches maxdist).
+static __device__ __forceinline__ uint32_t prefix_through_nth_bit(uint32_t m, int nth)
+{ // mask of all bit positions up to and including the nth (1-based) set bit of m
+  for (int k = 1; k < nth; k++) m &= m - 1;
+  const uint32_t bit = m & (0u - m);
+  return bit | (bit - 1u);
+}
+
+template <bool ACGT>
+__global__ __launch_bounds__(256) void consensus_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
+                                                         const uint32_t *__restrict__ cp, const int *__restrict__ snap_ptr,
+                                                         int4 *__restrict__ rt, int4 *__restrict__ tr)
+{
+  constexpr int P = ACGT ? 3 : 4, NQ = ACGT ? 4 : 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int trel = blockIdx.x * 4 + wave;
+  if (trel >= n_tiles) return;
+  const int snap = *snap_ptr;
+  const uint4 *t = db + (size_t)(tile_first + trel) * W4 * P * 64 + lane;
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  bool done = (snap <= 0);
+  for (int w4 = 0; w4 < W4; w4++) {
+    uint4 pl[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) pl[p] = t[(size_t)(w4 * P + p) * 64];
+    const uint32_t *s = cp + (size_t)w4 * 4 * NQ;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t k0, k1, k2, k3, M;     // planes of the four counters, mismatch plane
+      if (ACGT) {
+        const uint32_t rL = (&pl[0].x)[j], rH = (&pl[1].x)[j], rI = (&pl[2].x)[j];
+        const uint32_t qL = s[j * 4 + 0], qH = s[j * 4 + 1], qI = s[j * 4 + 2];
+        const uint32_t y = (rL ^ qL) | (rH ^ qH);
+        k1 = rI & qI; k0 = y & k1; k2 = 0; k3 = 0; M = k0;
+      } else {
+        const uint32_t rA = (&pl[0].x)[j], rC = (&pl[1].x)[j], rG = (&pl[2].x)[j], rT = (&pl[3].x)[j];
+        const uint32_t qA = s[j * 6 + 0], qC = s[j * 6 + 1], qG = s[j * 6 + 2], qT_ = s[j * 6 + 3], qv = s[j * 6 + 4], qa = s[j * 6 + 5];
+        const uint32_t rv = rA | rC | rG | rT;
+        const uint32_t nd = ~((rA ^ qA) | (rC ^ qC) | (rG ^ qG) | (rT ^ qT_));
+        k0 = nd & qa; k1 = nd & rv; k2 = (rA & qA) | (rC & qC) | (rG & qG) | (rT & qT_); k3 = rv & qv;
+        M = k3 & ~k0;
+      }
+      const int pm = __popc(M);
+      const int mcur = ACGT ? c0 : (c3 - c0);
+      if (!done && mcur + pm >= snap) {
+        const uint32_t pmask = prefix_through_nth_bit(M, snap - mcur);
+        t0 = c0 + __popc(k0 & pmask); t1 = c1 + __popc(k1 & pmask); t2 = c2 + __popc(k2 & pmask); t3 = c3 + __popc(k3 & pmask);
+        done = true;
+      }
+      c0 += __popc(k0); c1 += __popc(k1); c2 += __popc(k2); c3 += __popc(k3);
+    }
+  }
+  if (!done) { t0 = c0; t1 = c1; t2 = c2; t3 = c3; }
+  const size_t r = (size_t)trel * 64 + lane;
+  rt[r] = make_int4(c0, c1, c2, c3);
+  tr[r] = make_int4(t0, t1, t2, t3);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: score assembly and the ordered gate / heap replay
+// ------------------------------------------------------------------------------------------------------------
+// Assembles score[6] exactly as src/nearest.c:499-501 (default) or :464-469 (--acgt) from
+//   cnt = pair counters over all compared columns, rt = untruncated consensus counters over idx_c,
+//   rc  = the consensus counters the reference would hold in cq->res (possibly truncated), nn = cq->non_n.
+// Pair counters over idx_m + idx are cnt - rt because every query equals the consensus on idx_c.
+template <bool ACGT>
+static __device__ __forceinline__ void assemble_scores(const int4 cnt, const int4 rt, const int4 rc, int nn, int S[6], int &mism)
+{
+  if (ACGT) {
+    const int pmm = cnt.x - rt.x, pba = cnt.y - rt.y;   // mismatches / comparable sites outside idx_c
+    S[0] = (pba + rc.y) - (pmm + rc.x);
+    S[1] = pba + rc.y;
+    S[2] = S[0] - (rc.y - rc.x);
+    S[3] = nn;
+    S[4] = rc.x + (pmm - cnt.z);
+    S[5] = cnt.z;
+    mism = S[1] - S[0];
+  } else {
+    const int p0 = cnt.x - rt.x;
+    S[0] = p0 + rc.x;
+    S[1] = cnt.y - rt.y + rc.y;
+    S[2] = cnt.z - rt.z + rc.z;
+    S[3] = cnt.w - rt.w + rc.w;
+    S[4] = p0;
+    S[5] = nn;
+    mism = S[3] - S[0];
+  }
+}
+
+static __device__ __forceinline__ bool lex_better(const int a[6], const int b[6])
+{ // compare_q_item_score(a,b) < 0 (src/min_heap.c:41-47): a ranks strictly ahead of b
+#pragma unroll
+  for (int i = 0; i < 6; i++) { if (a[i] != b[i]) return a[i] > b[i]; }
+  return false;
+}
+
+static __device__ __forceinline__ bool entry_better(const int *a, const int *b)
+{
+  for (int i = 0; i < 6; i++) { if (a[i] != b[i]) return a[i] > b[i]; }
+  return false;
+}
+
+static __device__ void heap_sift_down(int *h, int n, int p)
+{ // heap_bubble_down, src/min_heap.c:119-133: root = worst; swap towards the worse child while p is better than it
+  for (;;) {
+    int c = 2 * p, pick = p;
+    for (int i = 0; i < 2; i++) if (c + i <= n && entry_better(h + pick * HEAP_ENTRY, h + (c + i) * HEAP_ENTRY)) pick = c + i;
+    if (pick == p) return;
+    for (int i = 0; i < HEAP_ENTRY; i++) { int tmp = h[p * HEAP_ENTRY + i]; h[p * HEAP_ENTRY + i] = h[pick * HEAP_ENTRY + i]; h[pick * HEAP_ENTRY + i] = tmp; }
+    p = pick;
+  }
+}
+
+static __device__ void heap_sift_up(int *h, int i)
+{ // heap_bubble_up, src/min_heap.c:135-147
+  while (i > 1) {
+    const int parent = i / 2;
+    if (!entry_better(h + parent * HEAP_ENTRY, h + i * HEAP_ENTRY)) return;
+    for (int k = 0; k < HEAP_ENTRY; k++) { int tmp = h[parent * HEAP_ENTRY + k]; h[parent * HEAP_ENTRY + k] = h[i * HEAP_ENTRY + k]; h[i * HEAP_ENTRY + k] = tmp; }
+    i = parent;
+  }
+}
+
+template <bool ACGT> static __device__ __forceinline__ int entry_mismatches(const int *e)
+{ return ACGT ? (e[1] - e[0]) : (e[3] - e[0]); }   // src/nearest.c:475 / :508
+
+static __device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// One wave per query.  The wave reads 64 consecutive pair counters of its query at a time, filters them with
+// bounds that can only tighten (T_ub = max mismatches held + 1, W = worst kept key: see DESIGN.md "gate"), and
+// serialises the survivors in reference order through the exact test of src/nearest.c:488-508.
+template <bool ACGT>
+__global__ __launch_bounds__(64) void replay_kernel(const int4 *__restrict__ cnt, int ppad, const int4 *__restrict__ rt, const int4 *__restrict__ tr,
+                                                     const int *__restrict__ nonn, int r_begin, int r_end, long long ord_base,
+                                                     int *__restrict__ heap_g, int *__restrict__ n_g, int *__restrict__ T_g,
+                                                     const int *__restrict__ snap_ptr, uint8_t *__restrict__ entered, int k)
+{
+  extern __shared__ int h[];                 // (k+1) entries of HEAP_ENTRY ints, slot 0 unused
+  const int q = blockIdx.x, lane = threadIdx.x;
+  int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
+  int n = n_g[q], T = T_g[q];
+  const int snap = *snap_ptr;
+  for (int i = lane; i < (n + 1) * HEAP_ENTRY; i += 64) h[i] = hg[i];
+  __syncthreads();
+  bool full = (n == k);
+  int W[6] = {0, 0, 0, 0, 0, 0};
+  int Tub = T;
+  if (full) {
+    int mx = 0;
+    for (int s = 1 + lane; s <= n; s += 64) mx = max(mx, entry_mismatches<ACGT>(h + s * HEAP_ENTRY));
+    Tub = wave_max(mx) + 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) W[i] = h[HEAP_ENTRY + i];
+  }
+  const int4 *crow = cnt + (size_t)q * ppad;
+  bool dirty = false;
+  for (int base = r_begin; base < r_end; base += 64) {
+    const int r = base + lane;
+    const bool valid = r < r_end;
+    int S[6] = {0, 0, 0, 0, 0, 0}, m = 0x7fffffff;
+    if (valid) {
+      const int4 c = crow[r], a = rt[r];
+      const int mc_true = ACGT ? a.x : (a.w - a.x);
+      const int4 rc = (mc_true >= snap) ? tr[r] : a;     // what cq->res holds after src/nearest.c:431-432
+      assemble_scores<ACGT>(c, a, rc, nonn[r], S, m);
+    }
+    bool cand = valid && m < Tub && (!full || lex_better(S, W));
+    unsigned long long mask = __ballot(cand);
+    while (mask) {
+      const int i = __ffsll((long long)mask) - 1;
+      int Si[6];
+#pragma unroll
+      for (int s = 0; s < 6; s++) Si[s] = __shfl(S[s], i);
+      const int mi = __shfl(m, i);
+      const bool accept = (mi < T) && (!full || lex_better(Si, W));   // src/nearest.c:488-496 + heap_insert :93-117
+      if (!accept) { mask &= mask - 1; continue; }
+      if (lane == 0) {
+        const long long ord = ord_base + (base + i - r_begin);
+        const int slot = full ? 1 : n + 1;
+        int *e = h + slot * HEAP_ENTRY;
+#pragma unroll
+        for (int s = 0; s < 6; s++) e[s] = Si[s];
+        e[6] = (int)(unsigned)(ord & 0xffffffffll); e[7] = (int)(ord >> 32);
+        if (full) heap_sift_down(h, n, 1); else heap_sift_up(h, n + 1);
+        entered[base + i] = 1;
+      }
+      if (!full) n++;
+      dirty = true;
+      __syncthreads();
+      const bool was_full = full;
+      full = (n == k);
+      if (full) {
+#pragma unroll
+        for (int s = 0; s < 6; s++) W[s] = h[HEAP_ENTRY + s];
+        T = entry_mismatches<ACGT>(W) + 1;               // src/nearest.c:506-508 / :474-475
+        if (!was_full) {
+          int mx = 0;
+          for (int s = 1 + lane; s <= n; s += 64) mx = max(mx, entry_mismatches<ACGT>(h + s * HEAP_ENTRY));
+          Tub = wave_max(mx) + 1;
+        }
+      }
+      cand = valid && lane > i && m < Tub && (!full || lex_better(S, W));
+      mask = __ballot(cand);
+    }
+  }
+  if (dirty) {
+    __syncthreads();
+    for (int i = lane; i < (n + 1) * HEAP_ENTRY; i += 64) hg[i] = h[i];
+    if (lane == 0) { n_g[q] = n; T_g[q] = T; }
+  }
+}
+
+__global__ void snapshot_kernel(const int *__restrict__ T, int nq, int *__restrict__ snap)
+{ // cq->max_incompatible = max over heaps (src/nearest.c:290-291)
+  __shared__ int red[256];
+  int v = -0x7fffffff;
+  for (int i = threadIdx.x; i < nq; i += 256) v = max(v, T[i]);
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+  if (threadIdx.x == 0) *snap = red[0];
+}
+
+__global__ void init_state_kernel(int *__restrict__ T, int *__restrict__ n, int nq, int nchar)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) { T[i] = nchar; n[i] = 0; }    // src/nearest.c:375,387 ; src/min_heap.c:56
+}
+
+// untruncated score vectors of a batch, for parity tests: out[(i*nq+q)*6+s]
+template <bool ACGT>
+__global__ void batch_scores_kernel(const int4 *__restrict__ cnt, int ppad, const int4 *__restrict__ rt, const int *__restrict__ nonn,
+                                    int r_begin, int n_ref, int nq, int *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (i >= n_ref) return;
+  const int r = r_begin + i;
+  int S[6], m;
+  assemble_scores<ACGT>(cnt[(size_t)q * ppad + r], rt[r], rt[r], nonn[r], S, m);
+  for (int s = 0; s < 6; s++) out[((size_t)i * nq + q) * 6 + s] = S[s];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+// Packs one character row restricted to `keep` (nullable: keep everything inside [lo,hi)) into query-plane words:
+// dst[(w4*4 + j)*NQ + plane].  is_poly marks query->idx columns (--acgt: fourth plane).
+int pack_query_row(const uint8_t *code_tab, const char *row, int nchar, int lo, int hi, const uint8_t *keep, const uint8_t *is_poly,
+                   bool acgt, int NQ, uint32_t *dst, int *bad_byte)
+{
+  for (int s = lo; s < hi; s++) {
+    if (keep && !keep[s]) continue;
+    const uint8_t code = code_tab[(unsigned char)row[s]];
+    if (code == 0xFF) { *bad_byte = (unsigned char)row[s]; return -1; }
+    if (!code) continue;
+    const int w = s >> 5, b = s & 31;
+    uint32_t *d = dst + (size_t)w * NQ;      // (w4*4+j) == w
+    const bool one = (code & (code - 1)) == 0;
+    if (acgt) {
+      if (!one) continue;
+      const uint32_t two = code == 2 ? 1u : code == 4 ? 2u : code == 8 ? 3u : 0u;
+      d[0] |= (two & 1u) << b; d[1] |= (two >> 1) << b; d[2] |= 1u << b;
+      if (is_poly && is_poly[s]) d[3] |= 1u << b;
+    } else {
+      for (int p = 0; p < 4; p++) d[p] |= (uint32_t)((code >> p) & 1u) << b;
+      d[4] |= 1u << b;
+      if (one) d[5] |= 1u << b;
+    }
+  }
+  return 0;
+}
+
+int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, const uint32_t *qp, int nq_pad, int4 *out, int ppad, double bytes)
+{
+  if (n_tiles <= 0) return 0;
+  dim3 grid((unsigned)(nq_pad / c->qt), (unsigned)((n_tiles + 3) / 4)), block(256);
+  ScanEvt ev{};
+  if (c->profile) {
+    HIPCHK(c, hipEventCreate(&ev.a)); HIPCHK(c, hipEventCreate(&ev.b));
+    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+  }
+#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, c->stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad)
+  if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan_acgt_kernel, 8); break; case 32: LAUNCH(scan_acgt_kernel, 32); break; default: LAUNCH(scan_acgt_kernel, 16); } }
+  else         { switch (c->qt) { case 8: LAUNCH(scan_iupac_kernel, 8); break; case 32: LAUNCH(scan_iupac_kernel, 32); break; default: LAUNCH(scan_iupac_kernel, 16); } }
+#undef LAUNCH
+  HIPCHK(c, hipGetLastError());
+  if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, c->stream)); ev.bytes = bytes; c->evts.push_back(ev); }
+  return 0;
+}
+
+int collect_events(uvaia_gpu_ctx *c)
+{
+  for (auto &e : c->evts) {
+    HIPCHK(c, hipEventSynchronize(e.b));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e.a, e.b));
+    c->scan_ms += ms; c->scan_bytes += e.bytes; c->scan_launches++;
+    hipEventDestroy(e.a); hipEventDestroy(e.b);
+  }
+  c->evts.clear();
+  return 0;
+}
+
+// One batch = one pool of the reference (src/nearest.c:288-306), on tiles [tile_first, tile_first+n_tiles) of `tiles`;
+// references r_begin..r_end-1 (relative to the first tile) are the batch, in order.
+int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, long long tile_first, int n_tiles, int r_begin, int r_end,
+              long long ord_base, uint8_t *entered_tile0)
+{
+  if (r_end <= r_begin) {   // an empty trailing batch only refreshes cq->max_incompatible (src/nearest.c:290-291)
+    return 0;
+  }
+  const int ppad = n_tiles * 64;
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap);
+  if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  HIPCHK(c, hipGetLastError());
+  const double bytes = (double)(r_end - r_begin) * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
+  int rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq_pad, c->d_cnt, ppad, bytes);
+  if (rc) return rc;
+  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
+  else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
+  HIPCHK(c, hipGetLastError());
+  c->last_tiles = tiles; c->last_nonn = nonn_tile0; c->last_n = r_end - r_begin; c->last_rbegin = r_begin; c->last_ppad = ppad;
+  return 0;
+}
+
+// stage + pack n_ref rows (either scattered pointers or one pitched block) into `tiles` starting at slot0
+int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t rows_pitch, const int *non_n, int n_ref,
+              uint4 *tiles, int *nonn_dev, long long slot0)
+{
+  for (int done = 0; done < n_ref; done += PACK_CHUNK) {
+    const int m = std::min(PACK_CHUNK, n_ref - done);
+    for (int i = 0; i < m; i++) {
+      const char *src = seq ? seq[done + i] : rows + (size_t)(done + i) * rows_pitch;
+      if (!src) return fail(c, UVAIA_GPU_EINVAL, "NULL sequence at position %d", done + i);
+      memcpy(c->h_stage + (size_t)i * c->pitch, src, (size_t)c->nchar);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, c->h_stage, (size_t)m * c->pitch, hipMemcpyHostToDevice, c->stream));
+    const long long s0 = slot0 + done, t0 = s0 / 64, t1 = (s0 + m - 1) / 64;
+    const int nblk = (int)(t1 - t0 + 1);
+    int *nn_out = non_n ? nullptr : nonn_dev;
+    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, c->d_err);
+    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    if (non_n) HIPCHK(c, hipMemcpyAsync(nonn_dev + s0, non_n + done, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // h_stage is reused by the next round
+  }
+  int bad = 0;
+  HIPCHK(c, hipMemcpy(&bad, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (bad) {
+    HIPCHK(c, hipMemset(c->d_err, 0, sizeof(int)));
+    return fail(c, UVAIA_GPU_EALPHABET, "a reference sequence holds a byte outside ACGT / MRWSYKVHDB / NX-?O.");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *uvaia_gpu_last_error(const uvaia_gpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_error.c_str(); }
+
+void uvaia_gpu_close(uvaia_gpu_ctx *c)
+{
+  if (!c) return;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  void *dev[] = {c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+                 c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
+  for (void *p : dev) if (p) hipFree(p);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size, int device, size_t max_pool)
+{
+  if (!out) return fail(nullptr, UVAIA_GPU_EINVAL, "ctx is NULL");
+  *out = nullptr;
+  if (!q || q->n_query < 1 || q->nchar < 1 || !q->seq || !q->consensus) return fail(nullptr, UVAIA_GPU_EINVAL, "empty or incomplete query set");
+  if ((q->n_idx_c && !q->idx_c) || (q->n_idx_m && !q->idx_m) || (q->n_idx && !q->idx)) return fail(nullptr, UVAIA_GPU_EINVAL, "index arrays missing");
+  if (max_pool < 1) return fail(nullptr, UVAIA_GPU_EINVAL, "max_pool must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, UVAIA_GPU_ENODEV, "no HIP device available: the MI355X engine has no CPU fallback");
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= ndev) return fail(nullptr, UVAIA_GPU_ENODEV, "device %d out of range (%d devices)", device, ndev);
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, UVAIA_GPU_ENODEV, "hipSetDevice(%d) failed", device);
+
+  uvaia_gpu_ctx *c = new uvaia_gpu_ctx();
+  c->device = device;
+  c->nq = q->n_query; c->nchar = q->nchar; c->acgt = q->acgt ? 1 : 0; c->trim = q->trim;
+  c->P = c->acgt ? 3 : 4; c->NQ = c->acgt ? 4 : 6;
+  c->W = (c->nchar + 31) / 32; c->W4 = (c->W + 3) / 4;
+  c->k = heap_size < 2 ? 2 : heap_size;                      // src/min_heap.c:58
+  c->qt = 16;
+  const char *env_qt = getenv("UVAIA_GPU_QT");
+  if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
+  c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
+  c->max_pool = max_pool; c->pool_pad = ((max_pool + 63) / 64) * 64 + 64;
+  c->pitch = ((size_t)c->nchar + 63) / 64 * 64;
+  if ((size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) > 160 * 1024) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "nbest=%d does not fit the per-query LDS heap (max 5119)", heap_size); }
+
+#define OPENCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int code_ = fail(nullptr, e_ == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); uvaia_gpu_close(c); return code_; } } while (0)
+  OPENCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  uint8_t code_tab[256]; fill_code_table(code_tab);
+  OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
+
+  // ---- query planes (trimmed: sites outside [trim, nchar-trim) never count, src/fastaseq.c:744,750,763)
+  const int lo = (int)std::min<size_t>(c->trim, (size_t)c->nchar), hi = std::max(lo, c->nchar - (int)c->trim);
+  const size_t row_words = (size_t)c->W4 * 4 * c->NQ;
+  std::vector<uint8_t> in_c(c->nchar, 0), in_m(c->nchar, 0), in_p(c->nchar, 0);
+  for (int i = 0; i < q->n_idx_c; i++) if (q->idx_c[i] < (size_t)c->nchar) in_c[q->idx_c[i]] = 1;
+  for (int i = 0; i < q->n_idx_m; i++) if (q->idx_m[i] < (size_t)c->nchar) in_m[q->idx_m[i]] = 1;
+  for (int i = 0; i < q->n_idx; i++)   if (q->idx[i]   < (size_t)c->nchar) in_p[q->idx[i]] = 1;
+  std::vector<uint32_t> qp((size_t)c->nq_pad * row_words, 0u), cp(row_words, 0u), cpm(row_words, 0u), qpoly((size_t)c->nq_pad * row_words, 0u);
+  int bad = 0;
+  for (int i = 0; i < c->nq; i++) {
+    if (!q->seq[i]) { uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", i); }
+    if (pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, nullptr, in_p.data(), c->acgt, c->NQ, qp.data() + (size_t)i * row_words, &bad) ||
+        pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, in_p.data(), in_p.data(), c->acgt, c->NQ, qpoly.data() + (size_t)i * row_words, &bad)) {
+      uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EALPHABET, "query %d holds byte 0x%02x outside the supported alphabet", i, bad);
+    }
+  }
+  if (pack_query_row(code_tab, q->consensus, c->nchar, 0, c->nchar, in_c.data(), nullptr, c->acgt, c->NQ, cp.data(), &bad) ||
+      pack_query_row(code_tab, q->consensus, c->nchar, 0, c->nchar, in_m.data(), nullptr, c->acgt, c->NQ, cpm.data(), &bad)) {
+    uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EALPHABET, "consensus holds byte 0x%02x outside the supported alphabet", bad);
+  }
+  OPENCHK(hipMalloc(&c->d_qp, qp.size() * 4)); OPENCHK(hipMemcpy(c->d_qp, qp.data(), qp.size() * 4, hipMemcpyHostToDevice));
+  OPENCHK(hipMalloc(&c->d_qpoly, qpoly.size() * 4)); OPENCHK(hipMemcpy(c->d_qpoly, qpoly.data(), qpoly.size() * 4, hipMemcpyHostToDevice));
+  OPENCHK(hipMalloc(&c->d_cp, cp.size() * 4)); OPENCHK(hipMemcpy(c->d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+  OPENCHK(hipMalloc(&c->d_cpm, cpm.size() * 4)); OPENCHK(hipMemcpy(c->d_cpm, cpm.data(), cpm.size() * 4, hipMemcpyHostToDevice));
+
+  // ---- state
+  OPENCHK(hipMalloc(&c->d_heap, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_n, (size_t)c->nq * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_T, (size_t)c->nq * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_snap, sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_err, sizeof(int)));
+  OPENCHK(hipMemset(c->d_err, 0, sizeof(int)));
+  // ---- batch buffers
+  const size_t tile_u4 = (size_t)c->W4 * c->P * 64;
+  OPENCHK(hipMalloc(&c->d_batch, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
+  OPENCHK(hipMemset(c->d_batch, 0, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
+  OPENCHK(hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
+  OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_cnt, (size_t)c->nq_pad * c->pool_pad * sizeof(int4)));
+  OPENCHK(hipMalloc(&c->d_rt, c->pool_pad * sizeof(int4)));
+  OPENCHK(hipMalloc(&c->d_tr, c->pool_pad * sizeof(int4)));
+  OPENCHK(hipMalloc(&c->d_entered, c->pool_pad)); c->entered_cap = c->pool_pad;
+  OPENCHK(hipMalloc(&c->d_stage, (size_t)PACK_CHUNK * c->pitch));
+  OPENCHK(hipHostMalloc(&c->h_stage, (size_t)PACK_CHUNK * c->pitch, hipHostMallocDefault));
+  memset(c->h_stage, 'N', (size_t)PACK_CHUNK * c->pitch);
+  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  if (lds > 64 * 1024) {
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+#undef OPENCHK
+  int rc = uvaia_gpu_reset(c);
+  if (rc) { g_open_error = c->err; uvaia_gpu_close(c); return rc; }
+  *out = c;
+  return UVAIA_GPU_OK;
+}
+
+int uvaia_gpu_reset(uvaia_gpu_ctx *c)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipMemsetAsync(c->d_heap, 0, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), c->stream));
+  hipLaunchKernelGGL(init_state_kernel, dim3((c->nq + 255) / 256), dim3(256), 0, c->stream, c->d_T, c->d_n, c->nq, c->nchar);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int uvaia_gpu_heap_slots(const uvaia_gpu_ctx *c) { return c ? c->k : 0; }
+int uvaia_gpu_n_query(const uvaia_gpu_ctx *c) { return c ? c->nq : 0; }
+size_t uvaia_gpu_packed_bytes_per_ref(const uvaia_gpu_ctx *c) { return c ? (size_t)c->W4 * 16 * c->P : 0; }
+
+int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (qt == 0) qt = 16;
+  if (qt != 8 && qt != 16 && qt != 32) return fail(c, UVAIA_GPU_EINVAL, "query tile must be 8, 16 or 32");
+  c->qt = qt;
+  return 0;
+}
+
+int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, int n_ref, int64_t ordinal0, uint8_t *entered)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (n_ref < 0 || (n_ref > 0 && !seq)) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
+  if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
+  if (n_ref == 0) return 0;
+  int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, 0);
+  if (rc) return rc;
+  const int n_tiles = (n_ref + 63) / 64;
+  HIPCHK(c, hipMemsetAsync(c->d_entered, 0, (size_t)n_tiles * 64, c->stream));
+  rc = run_batch(c, c->d_batch, c->d_batch_nonn, 0, n_tiles, 0, n_ref, ordinal0, c->d_entered);
+  if (rc) return rc;
+  if (entered) HIPCHK(c, hipMemcpyAsync(entered, c->d_entered, (size_t)n_ref, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return collect_events(c);
+}
+
+int uvaia_gpu_drain(uvaia_gpu_ctx *c, int *n_items, int *max_incompatible, int *scores, int64_t *ordinals)
+{
+  if (!c || !n_items || !scores || !ordinals) return c ? fail(c, UVAIA_GPU_EINVAL, "NULL output") : UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t ne = (size_t)c->nq * (c->k + 1);
+  std::vector<int> h(ne * HEAP_ENTRY), T(c->nq);
+  HIPCHK(c, hipMemcpy(h.data(), c->d_heap, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(n_items, c->d_n, (size_t)c->nq * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(T.data(), c->d_T, (size_t)c->nq * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < ne; e++) {
+    for (int s = 0; s < 6; s++) scores[e * 6 + s] = h[e * HEAP_ENTRY + s];
+    ordinals[e] = (int64_t)(((uint64_t)(uint32_t)h[e * HEAP_ENTRY + 7] << 32) | (uint32_t)h[e * HEAP_ENTRY + 6]);
+  }
+  if (max_incompatible) memcpy(max_incompatible, T.data(), (size_t)c->nq * sizeof(int));
+  return collect_events(c);
+}
+
+int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (cap <= c->db_cap) return 0;
+  if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "reserve the database before appending to it");
+  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); c->d_db = nullptr; c->d_db_nonn = nullptr; }
+  const size_t tiles = (cap + 63) / 64 + 1, tile_u4 = (size_t)c->W4 * c->P * 64;
+  HIPCHK(c, hipMalloc(&c->d_db, tiles * tile_u4 * sizeof(uint4)));
+  HIPCHK(c, hipMemset(c->d_db, 0, tiles * tile_u4 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_nonn, tiles * 64 * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
+  c->db_cap = tiles * 64 - 64;
+  if (c->entered_cap < tiles * 64) {
+    hipFree(c->d_entered); c->d_entered = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_entered, tiles * 64)); c->entered_cap = tiles * 64;
+  }
+  return 0;
+}
+
+static int db_append_common(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t pitch, const int *non_n, int n_ref)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (n_ref < 0) return fail(c, UVAIA_GPU_EINVAL, "negative count");
+  if (n_ref == 0) return 0;
+  if (c->db_n + (size_t)n_ref > c->db_cap) {
+    if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "database capacity %zu exceeded: call uvaia_gpu_db_reserve first", c->db_cap);
+    int rc = uvaia_gpu_db_reserve(c, (size_t)n_ref); if (rc) return rc;
+  }
+  int rc = pack_rows(c, seq, rows, pitch, non_n, n_ref, c->d_db, c->d_db_nonn, (long long)c->db_n);
+  if (rc) return rc;
+  c->db_n += (size_t)n_ref;
+  return 0;
+}
+
+int uvaia_gpu_db_append(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, int n_ref)
+{ if (c && n_ref > 0 && !seq) return fail(c, UVAIA_GPU_EINVAL, "NULL seq"); return db_append_common(c, seq, nullptr, 0, non_n, n_ref); }
+
+int uvaia_gpu_db_append_block(uvaia_gpu_ctx *c, const char *rows, size_t pitch, const int *non_n, int n_ref)
+{
+  if (c && n_ref > 0 && (!rows || pitch < (size_t)c->nchar)) return fail(c, UVAIA_GPU_EINVAL, "bad block");
+  return db_append_common(c, nullptr, rows, pitch, non_n, n_ref);
+}
+
+size_t uvaia_gpu_db_size(const uvaia_gpu_ctx *c) { return c ? c->db_n : 0; }
+
+int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, uint8_t *entered)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (pool < 1 || pool > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "pool must be in [1, max_pool=%zu]", c->max_pool);
+  if (!c->db_n) return 0;
+  HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
+  for (size_t a = 0; a < c->db_n; a += pool) {
+    const size_t b = std::min(c->db_n, a + pool);
+    const long long tf = (long long)(a / 64);
+    const int n_tiles = (int)((b + 63) / 64 - a / 64);
+    const int rb = (int)(a - (size_t)tf * 64), re = (int)(b - (size_t)tf * 64);
+    int rc = run_batch(c, c->d_db, c->d_db_nonn + tf * 64, tf, n_tiles, rb, re, ordinal0 + (long long)a - rb + rb, c->d_entered + tf * 64);
+    if (rc) return rc;
+  }
+  if (entered) {
+    HIPCHK(c, hipMemcpyAsync(entered, c->d_entered, c->db_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return collect_events(c);
+  }
+  return 0;
+}
+
+int uvaia_gpu_sync(uvaia_gpu_ctx *c)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return collect_events(c);
+}
+
+int uvaia_gpu_last_batch_scores(uvaia_gpu_ctx *c, int *out, int n_ref)
+{
+  if (!c || !out) return UVAIA_GPU_EINVAL;
+  if (n_ref != c->last_n || !c->last_nonn) return fail(c, UVAIA_GPU_ESTATE, "last batch held %d references, not %d", c->last_n, n_ref);
+  int *d_out = nullptr;
+  const size_t bytes = (size_t)n_ref * c->nq * 6 * sizeof(int);
+  HIPCHK(c, hipMalloc(&d_out, bytes));
+  dim3 grid((n_ref + 255) / 256, c->nq);
+  if (c->acgt) hipLaunchKernelGGL((batch_scores_kernel<true>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->d_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
+  else         hipLaunchKernelGGL((batch_scores_kernel<false>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->d_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(c, UVAIA_GPU_EHIP, "batch_scores: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int uvaia_gpu_scan_stats(uvaia_gpu_ctx *c, double *ms, long long *launches, double *bytes, int reset)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  int rc = collect_events(c); if (rc) return rc;
+  if (ms) *ms = c->scan_ms;
+  if (launches) *launches = c->scan_launches;
+  if (bytes) *bytes = c->scan_bytes;
+  if (reset) { c->scan_ms = 0; c->scan_bytes = 0; c->scan_launches = 0; }
+  return 0;
+}
+
+int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radius, int *mindist)
+{
+  (void)seq; (void)n_ref; (void)radius; (void)mindist;
+  return fail(c, UVAIA_GPU_ESTATE, "radius search is not built yet");
+}
+
+}  // extern "C"

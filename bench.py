@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- uvaia nearest-neighbour hot path on MI355X: reference sequences scored per second.
+
+One "step" = one complete nearest-neighbour search: every reference of the HBM-resident packed database is scored
+against the whole resident query set and passed through the ordered gate + top-k heaps (what `uvaia` does for one
+reference file, src/nearest.c:249-330 of the reference), heaps reset between steps.  Inputs are synthetic
+SARS-CoV-2-shaped alignments (uvaia_amd/csrc/host/synth.c, seed 20241008) and are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N=1 runs BASELINE.json config[1]: 1 000 queries x 100 000 references x 29 903 columns, 4-bit IUPAC planes, top-k 100.
+With N>1 every rank holds its own 100 000-reference shard of the database (weak scaling, block-cyclic in stream order).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+QUERY_INDEX0 = 1 << 40           # queries come from the same process, disjoint sequence numbers
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--refs", type=int, default=100000, help="references per GPU")
+    ap.add_argument("--nbest", type=int, default=100)
+    ap.add_argument("--pool", type=int, default=65536, help="batch size (the reference's --pool)")
+    ap.add_argument("--mode", choices=["iupac", "acgt"], default="iupac")
+    ap.add_argument("--preset", type=int, default=0, help="0 = bundled-like N content, 1 = clean")
+    ap.add_argument("--nchar", type=int, default=29903)
+    ap.add_argument("--seed", type=int, default=20241008)
+    ap.add_argument("--qt", type=int, default=0, help="query tile of the scan kernel (8/16/32, 0 = default)")
+    ap.add_argument("--cpu-refs", type=int, default=1536, help="references in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from uvaia_amd import capi, hostlib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- inputs: queries (host C preparation, as the command line does) and the resident packed database
+    gen = hostlib.Synth(args.nchar, seed=args.seed, preset=args.preset)
+    qseqs, _ = gen.generate_bytes(QUERY_INDEX0, args.queries)
+    qnames = ["query_%d" % i for i in range(args.queries)]
+    pq = hostlib.PreparedQuery(qseqs, qnames, acgt=(args.mode == "acgt"))
+    pool = min(args.pool, args.refs)
+    eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank)
+    if args.qt:
+        eng.set_query_tile(args.qt)
+    eng.db_reserve(args.refs)
+    t0 = time.time()
+    first = rank * args.refs                      # this rank's shard of the stream
+    chunk = 8192
+    for a in range(0, args.refs, chunk):
+        n = min(chunk, args.refs - a)
+        rows, non_n = gen.generate(first + a, n)
+        eng.db_append_block(rows, non_n)
+    load_s = time.time() - t0
+    bytes_per_ref = eng.packed_bytes_per_ref()
+
+    # ---- timed region
+    def step():
+        eng.reset()
+        eng.search_resident(pool, ordinal0=first, want_entered=False)
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    eng.scan_stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_launches, scan_bytes = eng.scan_stats(reset=True)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / max(1, args.steps)
+    value = world * args.refs * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (pair scan): algorithmic bytes per launch / mean launch time (HIP events)
+    launches = max(1, scan_launches)
+    avg_ms = scan_ms / launches
+    achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    W = (args.nchar + 31) // 32
+    ops_per_pair_word = 15 if args.mode == "iupac" else 8
+    valu_ops = float(args.refs) * pq.ntax * W * ops_per_pair_word * args.steps       # lane-ops in the timed region
+    valu_rate = valu_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "kernel": "scan_iupac_kernel" if args.mode == "iupac" else "scan_acgt_kernel",
+        "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
+        "algorithmic_bytes_per_launch": scan_bytes / launches,
+        "valu_tlaneops_per_s": round(valu_rate, 2),
+        "note": "at %d resident queries the scan is integer-VALU bound, not HBM bound (DESIGN.md)" % pq.ntax,
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle's restatement of the reference loops on a bounded sample
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and args.cpu_refs > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        n_s = min(args.cpu_refs, args.refs)
+        sample, _ = gen.generate_bytes(first, n_s)
+        snames = ["ref_%d" % i for i in range(n_s)]
+        oq = O.Query(qseqs, qnames, acgt=(args.mode == "acgt"))
+        cores = O.lib().orc_max_threads()
+        t0 = time.perf_counter()
+        gold = O.search(oq, sample, snames, pool=min(pool, n_s), nbest=args.nbest, ambig_r=0.5)
+        cpu_s = time.perf_counter() - t0
+        cpu = {"value": round(n_s / cpu_s, 2), "unit": "ref-seqs/s", "cores": cores, "kind": "port",
+               "sample": "first %d references of the same database vs the same %d queries, pool %d, OpenMP over %d threads, %.1f s"
+                         % (n_s, oq.ntax, min(pool, n_s), cores, cpu_s)}
+        if not args.no_parity:      # the same sample through the GPU engine must give the same heaps
+            eng.reset()
+            with pq.open_engine(nbest=args.nbest, max_pool=min(pool, n_s), device=local_rank) as e2:
+                if args.qt:
+                    e2.set_query_tile(args.qt)
+                e2.push(sample)
+                n, T, sc, od = e2.drain()
+            rows = capi.finalise_heaps(n, sc, od)
+            ok = list(T) == gold.final_T and all(
+                rows[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(oq.ntax))
+            parity = bool(ok)
+
+    if rank == 0:
+        out = {
+            "metric": "ref-seqs scored/sec", "value": round(value, 2), "unit": "ref-seqs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 bit-planes / int32 counts", "data": "synthetic (seed %d, preset %d)" % (args.seed, args.preset),
+            "config": {"workload": "BASELINE config[1]: %d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d"
+                                   % (pq.ntax, args.refs, args.nchar, "4-bit IUPAC planes" if args.mode == "iupac" else "2-bit + validity planes (--acgt)", args.nbest, pool),
+                       "queries": pq.ntax, "refs_per_gpu": args.refs, "nchar": args.nchar, "nbest": args.nbest, "pool": pool,
+                       "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity_check_on_sample": parity,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

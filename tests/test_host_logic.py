@@ -1,0 +1,141 @@
+"""CPU tests of the product's host C code (uvaia_amd/csrc/host) against the oracle's literal restatement."""
+import ctypes as C
+import gzip
+import lzma
+import os
+
+import numpy as np
+import pytest
+
+import fixtures as F
+import oracle_lib as O
+from uvaia_amd import hostlib as H
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    H.build_library()
+
+
+def _same_query(a, b):
+    assert a.ntax == b.ntax and a.nchar == b.nchar and a.trim == b.trim and a.dist == b.dist
+    assert a.names == b.names
+    assert a.seqs == b.seqs
+    if a.ntax:
+        assert a.consensus == b.consensus
+        for f in ("idx_c", "idx_m", "idx"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("trim", [0, 230, 20000])
+def test_query_preparation_bundled(bundled_db, acgt, trim):
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:40]
+    qs = [by[n] for n in qn]
+    _same_query(H.PreparedQuery(qs, qn, trim=trim, acgt=acgt), O.Query(qs, qn, trim=trim, acgt=acgt))
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("keep", [False, True])
+@pytest.mark.parametrize("ball", [False, True])
+def test_query_preparation_with_redundancy(acgt, keep, ball):
+    # near-duplicates with different N patterns: exercises exclude_redundant_query_sequences
+    base, root, cols = F.synth_alignment(12, 1500, seed=3, p_snp=0.004)
+    rng = np.random.default_rng(9)
+    qs = []
+    for s in base:
+        qs.append(s)
+        t = bytearray(s)
+        a, ln = int(rng.integers(0, 1400)), int(rng.integers(1, 90))
+        t[a:a + ln] = b"N" * ln
+        qs.append(bytes(t))
+        qs.append(s)                       # exact duplicate
+    names = ["q%d" % i for i in range(len(qs))]
+    a = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    b = O.Query(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    _same_query(a, b)
+    if ball or keep:
+        assert a.ntax < len(qs)
+
+
+def test_low_quality_queries_are_dropped():
+    good, _, _ = F.synth_alignment(3, 600, seed=1)
+    bad = b"N" * 400 + good[0][400:]
+    qs = [good[0], bad, good[1], b"ACGT" + b"-" * 596, good[2]]
+    names = list("abcde")
+    a, b = H.PreparedQuery(qs, names), O.Query(qs, names)
+    _same_query(a, b)
+    assert sorted(a.names) == ["a", "c", "e"]
+
+
+def test_host_heap_matches_oracle_heap():
+    L, OL = H.load_library(), O.lib()
+    OL.orc_heap_new.restype = C.POINTER(O.OrcItem)   # placeholder to keep ctypes happy; real signature below
+    class OrcHeap(C.Structure):
+        _fields_ = [("seq", C.POINTER(O.OrcItem)), ("heap_size", C.c_int), ("n", C.c_int), ("max_incompatible", C.c_int)]
+    OL.orc_heap_new.restype = C.POINTER(OrcHeap)
+    OL.orc_heap_new.argtypes = [C.c_int]
+    OL.orc_heap_insert.restype = C.c_int
+    OL.orc_heap_insert.argtypes = [C.POINTER(OrcHeap), C.POINTER(O.OrcItem)]
+    OL.orc_heap_finalise.argtypes = [C.POINTER(OrcHeap)]
+    OL.orc_heap_del.argtypes = [C.POINTER(OrcHeap)]
+    rng = np.random.default_rng(2)
+    for size in (1, 2, 3, 7, 50):
+        for n_items in (0, 1, size - 1, size, size + 1, 5 * size + 3):
+            n_items = max(0, n_items)
+            h, o = L.new_heap_t(size), OL.orc_heap_new(size)
+            for i in range(n_items):
+                sc = [int(x) for x in rng.integers(0, 3, size=6)]       # tiny range: plenty of full ties
+                nm = ("s%d" % i).encode()
+                it = H.QItem((C.c_int * 6)(*sc), nm)
+                ot = O.OrcItem((C.c_int * 6)(*sc), nm, i)
+                assert bool(L.heap_insert(h, it)) == bool(OL.orc_heap_insert(o, C.byref(ot)))
+                assert h.contents.n == o.contents.n
+                for s in range(1, h.contents.n + 1):                    # same layout after every operation
+                    assert list(h.contents.seq[s].score) == list(o.contents.seq[s].score)
+                    assert h.contents.seq[s].name == o.contents.seq[s].name
+            if n_items != size - 1 or size == 1:                          # n == size-1 reads an unused slot in the reference
+                L.heap_finalise_heap_qsort(h); OL.orc_heap_finalise(o)
+                assert h.contents.heap_size == o.contents.heap_size
+                for s in range(h.contents.n):
+                    assert list(h.contents.seq[s].score) == list(o.contents.seq[s].score)
+                    assert h.contents.seq[s].name == o.contents.seq[s].name
+            L.del_heap_t(h); OL.orc_heap_del(o)
+
+
+def test_readfasta_streams_plain_gz_xz(tmp_path):
+    L = H.load_library()
+    recs = [("seq one", b"acgtnn--ACGT"), ("s2", b"AC GT\nAC"), ("third/3", b"NNNN")]
+    text = b"".join(b">" + n.encode() + b"\n" + s + b"\n\n" for n, s in recs)
+    paths = {"plain": tmp_path / "a.fa", "gz": tmp_path / "a.fa.gz", "xz": tmp_path / "a.fa.xz"}
+    paths["plain"].write_bytes(text)
+    with gzip.open(paths["gz"], "wb") as fh: fh.write(text)
+    with lzma.open(paths["xz"], "wb") as fh: fh.write(text)
+    want = [(n, s.replace(b" ", b"").replace(b"\n", b"").upper()) for n, s in recs]
+    for kind, p in paths.items():
+        r = L.new_readfasta(str(p).encode())
+        got = []
+        while True:
+            n = L.readfasta_next(r)
+            if n < 0:
+                break
+            got.append((r.contents.name.decode(), C.string_at(r.contents.seq, n)))
+        L.del_readfasta(r)
+        assert got == want, kind
+
+
+def test_generator_is_deterministic_and_shaped():
+    g = H.Synth(29903, seed=20241008, preset=0)
+    a, na = g.generate(1000, 64)
+    b, nb = g.generate(1032, 32)
+    assert np.array_equal(a[32:], b) and np.array_equal(na[32:], nb)      # sequence i depends only on (seed, i)
+    rows, non_n = g.generate(0, 2000)
+    frac_invalid = 1.0 - non_n / 29903.0
+    assert 0.10 < np.median(frac_invalid) < 0.25 and frac_invalid.max() < 0.5
+    assert set(np.unique(rows)) <= set(b"ACGTN-YRKMSWDHVB")
+    want = np.array([O.lib().orc_count_non_N(rows[i].tobytes(), 29903) for i in range(50)])
+    assert np.array_equal(want, non_n[:50])
+    clean = H.Synth(29903, seed=20241008, preset=1).generate(0, 500)[1]
+    assert np.median(1.0 - clean / 29903.0) < 0.03

@@ -1,0 +1,51 @@
+/*
+ * fastaseq.h -- streaming FASTA reader and the prepared query set (host side).
+ * Names, struct fields and call order follow the reference's src/fastaseq.h:32-48,70-83 for the nearest-neighbour path
+ * (the cluster/medoid half of that header serves uvaiaclust only and is not provided).
+ */
+#ifndef UVAIA_HOST_FASTASEQ_H
+#define UVAIA_HOST_FASTASEQ_H
+
+#include "utils.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct readfasta_struct *readfasta_t;
+typedef struct query_struct *query_t;
+
+struct readfasta_struct {
+  file_compress_t seqfile;
+  char *line_read, *next_name;
+  char *name, *seq;              /* current record; the caller may steal either pointer by setting it to NULL */
+  size_t linelength, seqlength;
+  bool newseq;
+};
+
+struct query_struct {
+  alignment aln;                 /* all query sequences, in memory */
+  char *consensus;               /* per column: 'N' no usable query, '#' queries disagree, else the shared character */
+  size_t *idx_c, *idx_m, *idx, trim;   /* constant & complete / constant with missing / polymorphic columns */
+  int n_idx_c, n_idx_m, n_idx, dist;
+  bool acgt;
+};
+
+/* one record per call; returns its length, or -1 once the file is exhausted */
+readfasta_t new_readfasta (const char *seqfilename);
+int readfasta_next (readfasta_t rfas);
+void del_readfasta (readfasta_t rfas);
+
+int quick_count_sequence_non_N (char *s, size_t nsites);   /* valid sites over the given span */
+
+query_t new_query_structure_from_fasta (char *filename, int trim, int dist, int acgt);
+query_t new_query_structure_from_alignment (alignment aln, int trim, int dist, int acgt);   /* takes ownership of aln */
+void del_query_structure (query_t qu);
+void create_query_indices (query_t qu);
+void reorder_query_structure (query_t qu);
+void exclude_redundant_query_sequences (query_t qu, int keep_more_resolved);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,46 @@
+/* gpu_glue.c -- see gpu_glue.h. */
+#include "gpu_glue.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+int
+uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int device, size_t max_pool)
+{
+  uvaia_gpu_query q;
+  memset (&q, 0, sizeof q);
+  q.n_query = query->aln->ntax;
+  q.nchar = query->aln->nchar;
+  q.seq = (const char *const *) query->aln->character->string;
+  q.consensus = query->consensus;
+  q.idx_c = query->idx_c; q.idx_m = query->idx_m; q.idx = query->idx;
+  q.n_idx_c = query->n_idx_c; q.n_idx_m = query->n_idx_m; q.n_idx = query->n_idx;
+  q.trim = query->trim;
+  q.acgt = query->acgt ? 1 : 0;
+  return uvaia_gpu_open (ctx, &q, heap_size, device, max_pool);
+}
+
+int
+uvaia_gpu_collect_heaps (uvaia_gpu_ctx *ctx, heap_t *heap, const char *(*name_of) (int64_t, void *), void *user)
+{
+  const int nq = uvaia_gpu_n_query (ctx), slots = uvaia_gpu_heap_slots (ctx);
+  int *n = (int *) malloc ((size_t) nq * sizeof (int)), *T = (int *) malloc ((size_t) nq * sizeof (int));
+  int *scores = (int *) malloc ((size_t) nq * (slots + 1) * UVAIA_GPU_NSCORE * sizeof (int));
+  int64_t *ord = (int64_t *) malloc ((size_t) nq * (slots + 1) * sizeof (int64_t));
+  int rc = (n && T && scores && ord) ? uvaia_gpu_drain (ctx, n, T, scores, ord) : UVAIA_GPU_ENOMEM;
+  for (int q = 0; q < nq && !rc; q++) {
+    heap_t h = heap[q];
+    if (h->heap_size != slots) { rc = UVAIA_GPU_EINVAL; break; }
+    for (int s = 1; s <= n[q]; s++) {
+      size_t e = (size_t) q * (slots + 1) + s;
+      free (h->seq[s].name);
+      const char *nm = name_of ? name_of (ord[e], user) : NULL;
+      h->seq[s].name = nm ? strdup (nm) : NULL;
+      memcpy (h->seq[s].score, scores + e * UVAIA_GPU_NSCORE, UVAIA_GPU_NSCORE * sizeof (int));
+    }
+    h->n = n[q];
+    h->max_incompatible = T[q];
+  }
+  free (n); free (T); free (scores); free (ord);
+  return rc;
+}

@@ -1,0 +1,230 @@
+/* seq_query.c -- implementation of fastaseq.h.
+ * Behaviour follows the reference (reader: src/fastaseq.c:410-486; query set: src/fastaseq.c:698-841); own code. */
+#include "fastaseq.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ reader */
+readfasta_t
+new_readfasta (const char *seqfilename)
+{
+  readfasta_t r = (readfasta_t) biomcmc_malloc (sizeof (struct readfasta_struct));
+  memset (r, 0, sizeof *r);
+  r->seqfile = biomcmc_open_compress (seqfilename, "r");
+  return r;
+}
+
+static void
+promote_pending_name (readfasta_t r)
+{
+  if (!r->next_name) return;
+  free (r->name);
+  r->name = r->next_name;
+  r->next_name = NULL;
+}
+
+int
+readfasta_next (readfasta_t r)
+{
+  if (!r->seqfile) return -1;
+  while (biomcmc_getline_compress (&r->line_read, &r->linelength, r->seqfile) != -1) {
+    char *line = r->line_read;
+    if (!nonempty_fasta_line (line)) continue;
+    char *header = strchr (line, '>');
+    if (header) {              /* a header closes the record being assembled (if any) */
+      header++;
+      r->newseq = true;
+      promote_pending_name (r);
+      size_t l = strlen (header);
+      r->next_name = (char *) biomcmc_malloc (l + 1);
+      memcpy (r->next_name, header, l + 1);
+      if (r->seqlength) return (int) r->seqlength;
+      continue;
+    }
+    if (r->newseq) { free (r->seq); r->seq = NULL; r->seqlength = 0; r->newseq = false; }
+    uppercase_string (remove_space_from_string (line));
+    size_t l = strlen (line);
+    r->seq = (char *) biomcmc_realloc (r->seq, r->seqlength + l + 1);
+    memcpy (r->seq + r->seqlength, line, l + 1);
+    r->seqlength += l;
+  }
+  biomcmc_close_compress (r->seqfile);
+  r->seqfile = NULL;
+  free (r->line_read); r->line_read = NULL;
+  promote_pending_name (r);
+  return (int) r->seqlength;
+}
+
+void
+del_readfasta (readfasta_t r)
+{
+  if (!r) return;
+  if (r->seqfile) biomcmc_close_compress (r->seqfile);
+  free (r->line_read); free (r->seq); free (r->next_name); free (r->name);
+  free (r);
+}
+
+int
+quick_count_sequence_non_N (char *s, size_t nsites)
+{
+  int n = 0;
+  for (size_t i = 0; i < nsites; i++) n += is_site_valid (s[i]);
+  return n;
+}
+
+static int
+count_acgt_sites (const char *s, size_t nsites)
+{
+  int n = 0;
+  for (size_t i = 0; i < nsites; i++) n += is_site_acgt (s[i]);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ query set */
+query_t
+new_query_structure_from_alignment (alignment aln, int trim, int dist, int acgt)
+{
+  query_t qu = (query_t) biomcmc_malloc (sizeof (struct query_struct));
+  memset (qu, 0, sizeof *qu);
+  qu->aln = aln;
+  qu->acgt = acgt != 0;
+  if (trim < 0) trim = 0;
+  if (trim > aln->nchar / 2.1) trim = (int) (aln->nchar / 2.1);       /* never trim away more than ~half */
+  qu->trim = (size_t) trim;
+  if (dist < 0) dist = 0;
+  if (dist > (aln->nchar - 2 * trim) / 10) dist = (aln->nchar - 2 * trim) / 10;
+  qu->dist = dist;
+  return qu;
+}
+
+query_t
+new_query_structure_from_fasta (char *filename, int trim, int dist, int acgt)
+{
+  return new_query_structure_from_alignment (read_fasta_alignment_from_file (filename, 0xf), trim, dist, acgt);
+}
+
+void
+del_query_structure (query_t qu)
+{
+  if (!qu) return;
+  free (qu->consensus); free (qu->idx_c); free (qu->idx_m); free (qu->idx);
+  del_alignment (qu->aln);
+  free (qu);
+}
+
+static inline int
+usable (const query_t qu, char c) { return qu->acgt ? is_site_acgt (c) : is_site_valid (c); }
+
+void
+create_query_indices (query_t qu)
+{ /* classify every column inside the trimmed window from what the usable query characters show there */
+  const int L = qu->aln->nchar, lo = (int) qu->trim, hi = L - (int) qu->trim, n = qu->aln->ntax;
+  char **s = qu->aln->character->string;
+  initialise_acgt ();
+  if (!qu->consensus) qu->consensus = (char *) biomcmc_malloc ((size_t) L);
+  memset (qu->consensus, 'N', (size_t) L);
+  size_t span = hi > lo ? (size_t) (hi - lo) : 0;
+  qu->idx_c = (size_t *) biomcmc_realloc (qu->idx_c, (span + 1) * sizeof (size_t));
+  qu->idx_m = (size_t *) biomcmc_realloc (qu->idx_m, (span + 1) * sizeof (size_t));
+  qu->idx   = (size_t *) biomcmc_realloc (qu->idx,   (span + 1) * sizeof (size_t));
+  qu->n_idx_c = qu->n_idx_m = qu->n_idx = 0;
+  for (int col = lo; col < hi; col++) {
+    char shared = 'N';
+    int missing = 0, j;
+    for (j = 0; j < n; j++) {
+      char c = s[j][col];
+      if (!usable (qu, c)) { missing = 1; continue; }
+      if (shared == 'N') shared = c;
+      else if (shared != c) break;           /* polymorphic: later sequences cannot change that */
+    }
+    if (j < n) { qu->consensus[col] = '#'; qu->idx[qu->n_idx++] = (size_t) col; }
+    else if (shared != 'N') {
+      qu->consensus[col] = shared;
+      if (missing) qu->idx_m[qu->n_idx_m++] = (size_t) col; else qu->idx_c[qu->n_idx_c++] = (size_t) col;
+    }
+  }
+  fprintf (stderr, "Query sequence alignment: %d segregating, %d non-segregating sites with indels, and %d constant sites (all are used in comparisons)\n",
+           qu->n_idx, qu->n_idx_m, qu->n_idx_c);
+}
+
+typedef struct { int key, pos; } keyed_pos;
+static int
+by_key_then_pos (const void *a, const void *b)
+{
+  const keyed_pos *x = (const keyed_pos *) a, *y = (const keyed_pos *) b;
+  return x->key != y->key ? (x->key < y->key ? -1 : 1) : x->pos - y->pos;
+}
+
+void
+reorder_query_structure (query_t qu)
+{ /* least resolved queries first (fewest usable sites inside the trimmed window); ties keep file order */
+  const int n = qu->aln->ntax;
+  const size_t span = (size_t) qu->aln->nchar - 2 * qu->trim;
+  keyed_pos *kp = (keyed_pos *) biomcmc_malloc ((size_t) (n > 0 ? n : 1) * sizeof *kp);
+  int *order = (int *) biomcmc_malloc ((size_t) (n > 0 ? n : 1) * sizeof (int));
+  for (int i = 0; i < n; i++) {
+    char *s = qu->aln->character->string[i] + qu->trim;
+    kp[i].pos = i;
+    kp[i].key = qu->acgt ? count_acgt_sites (s, span) : quick_count_sequence_non_N (s, span);
+  }
+  qsort (kp, (size_t) n, sizeof *kp, by_key_then_pos);
+  for (int i = 0; i < n; i++) order[i] = kp[i].pos;
+  char_vector_reorder_strings_from_external_order (qu->aln->character, order);
+  char_vector_reorder_strings_from_external_order (qu->aln->taxlabel, order);
+  free (kp); free (order);
+}
+
+/* do a and b differ at any polymorphic column where both are usable? */
+static int
+queries_conflict (const query_t qu, const char *a, const char *b)
+{
+  for (int j = 0; j < qu->n_idx; j++) {
+    char x = a[qu->idx[j]], y = b[qu->idx[j]];
+    if (qu->acgt ? is_site_acgt_distinct_pair (x, y) : (is_site_pair_valid (x, y) && x != y)) return 1;
+  }
+  return 0;
+}
+
+/* over the given columns: -1 a is usable somewhere b is not (only), +1 the converse, 0 same pattern, 0xff both */
+static int
+resolution_order (const query_t qu, const char *a, const char *b, const size_t *cols, int n_cols)
+{
+  int verdict = 0;
+  for (int j = 0; j < n_cols; j++) {
+    int ua = usable (qu, a[cols[j]]), ub = usable (qu, b[cols[j]]);
+    if (ua == ub) continue;
+    int side = ua > ub ? -1 : 1;
+    if (verdict == -side) return 0xff;
+    verdict = side;
+  }
+  return verdict;
+}
+
+void
+exclude_redundant_query_sequences (query_t qu, int keep_more_resolved)
+{
+  if (!qu->consensus) biomcmc_error ("I can only exclude sequences after indices are created");
+  const int n = qu->aln->ntax;
+  char **s = qu->aln->character->string;
+  int *alive = (int *) biomcmc_malloc ((size_t) (n > 0 ? n : 1) * sizeof (int)), n_alive = 0;
+  for (int i = 0; i < n; i++) alive[i] = 1;
+  for (int i = 0; i < n - 1; i++) for (int j = i + 1; j < n; j++) {
+    if (!alive[i] || !alive[j] || queries_conflict (qu, s[i], s[j])) continue;
+    int on_poly = resolution_order (qu, s[i], s[j], qu->idx, qu->n_idx);
+    if (on_poly > 1) continue;
+    int on_const = resolution_order (qu, s[i], s[j], qu->idx_m, qu->n_idx_m);
+    if (on_const > 1) continue;
+    if (!on_poly && !on_const) alive[j] = 0;          /* identical patterns: the later copy goes */
+    int sum = on_poly + on_const;                       /* <0: i more resolved; >0: j more resolved; 0: complementary */
+    if (!sum) continue;
+    int i_is_less_resolved = sum > 0;
+    if (keep_more_resolved) alive[i_is_less_resolved ? i : j] = 0;
+    else                    alive[i_is_less_resolved ? j : i] = 0;
+  }
+  for (int i = 0; i < n; i++) if (alive[i]) alive[n_alive++] = i;
+  char_vector_reduce_to_valid_strings (qu->aln->character, alive, n_alive);
+  char_vector_reduce_to_valid_strings (qu->aln->taxlabel, alive, n_alive);
+  qu->aln->ntax = n_alive;
+  free (alive);
+}

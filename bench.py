@@ -106,6 +106,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     scan_ms, scan_launches, scan_bytes = eng.scan_stats(reset=True)
+    admitted, demanded, dense_rescans = eng.replay_stats(reset=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -118,13 +119,15 @@ def main():
     avg_ms = scan_ms / launches
     achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     W = (args.nchar + 31) // 32
-    ops_per_pair_word = 15 if args.mode == "iupac" else 8
+    fullscan = os.environ.get("UVAIA_GPU_FULLSCAN", "0") not in ("", "0")
+    ops_per_pair_word = (15 if args.mode == "iupac" else 8) if fullscan else 6
     valu_ops = float(args.refs) * pq.ntax * W * ops_per_pair_word * args.steps       # lane-ops in the timed region
     valu_rate = valu_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "kernel": "scan_iupac_kernel" if args.mode == "iupac" else "scan_acgt_kernel",
+        "kernel": ("scan_%s_kernel" if fullscan else "scan2_%s_kernel") % args.mode,
+        "valu_ops_per_pair_word": ops_per_pair_word,
         "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
         "algorithmic_bytes_per_launch": scan_bytes / launches,
         "valu_tlaneops_per_s": round(valu_rate, 2),
@@ -171,6 +174,8 @@ def main():
                        "queries": pq.ntax, "refs_per_gpu": args.refs, "nchar": args.nchar, "nbest": args.nbest, "pool": pool,
                        "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2)},
             "roofline": roofline,
+            "replay": {"admissions_per_step": admitted // max(1, args.steps + args.warmup), "on_demand_per_step": demanded // max(1, args.steps + args.warmup),
+                       "dense_rescans_per_step": dense_rescans // max(1, args.steps + args.warmup)},
             "cpu_baseline": cpu,
             "parity_check_on_sample": parity,
         }

@@ -117,6 +117,9 @@ int uvaia_gpu_last_batch_scores (uvaia_gpu_ctx *ctx, int *out, int n_ref);
 /* device time (ms) and launch count of the dominant kernel (the pair scan), measured with HIP events on the
  * context's stream since the last call with reset != 0; bytes = algorithmic bytes those launches covered. */
 int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, double *algorithmic_bytes, int reset);
+/* counters of the ordered replay since the last reset: out[0] = admissions into heaps, out[1] = pairs whose remaining
+ * counters were evaluated on demand, out[2] = of those, evaluated by a dense rescan (ambiguity lists overflowed) */
+int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int reset);
 /* tuning knob: queries held per pass of the scan kernel (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
 /* bytes per packed reference in HBM */

@@ -206,3 +206,34 @@ def test_random_small_many_states(acgt):
         if q.ntax < 1:
             continue
         _assert_same_search(q, refs, int(rng.integers(1, 40)), int(rng.integers(1, 12)))
+
+
+def test_heavily_ambiguous_sequences_use_the_dense_rescan():
+    """Sequences with more partially ambiguous words than the per-sequence list holds: the replay must fall back to a dense
+    rescan for the on-demand counters and still agree with the oracle (text/partial matches decide the order here)."""
+    rng = np.random.default_rng(77)
+    L = 1600
+    refs, root, cols = F.synth_alignment(260, L, seed=31, p_snp=0.004, p_amb=0.03)      # ~48 ambiguous sites per sequence
+    qs, _, _ = F.synth_alignment(9, L, seed=32, root=root, poly_cols=cols, p_snp=0.004, p_amb=0.03)
+    qs += F.synth_alignment(3, L, seed=33, root=root, poly_cols=cols, p_snp=0.004, p_amb=0.0005)[0]   # and a few clean ones
+    q = O.Query(qs, _names(len(qs), "q"), ambig_q=1.0)
+    gold = O.search(q, refs, _names(len(refs)), pool=50, nbest=8, ambig_r=1.0)
+    with capi.Engine.from_query(q, nbest=8, max_pool=50) as eng:
+        for a in range(0, len(refs), 50):
+            eng.push(refs[a:a + 50])
+        n, T, sc, od = eng.drain()
+        admitted, demanded, dense = eng.replay_stats()
+    rows = capi.finalise_heaps(n, sc, od)
+    for iq in range(q.ntax):
+        assert rows[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]]
+    assert list(T) == gold.final_T
+    assert dense > 0 and demanded >= admitted > 0
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_four_counter_path_still_agrees(synth, acgt, monkeypatch):
+    """UVAIA_GPU_FULLSCAN=1 selects the four-counter scan + replay (kept for A/B measurements)."""
+    monkeypatch.setenv("UVAIA_GPU_FULLSCAN", "1")
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+    _assert_same_search(q, refs, 96, 9)

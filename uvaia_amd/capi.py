@@ -15,7 +15,7 @@ SYMBOLS = [
     "uvaia_gpu_open", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
     "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball",
-    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
+    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
 ]
 
 
@@ -81,6 +81,7 @@ def load_library():
         "uvaia_gpu_ball": (C.c_int, [vp, pp, C.c_int, C.c_int, pi]),
         "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
         "uvaia_gpu_scan_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]),
+        "uvaia_gpu_replay_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.c_int]),
         "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
     }
@@ -217,6 +218,12 @@ class Engine:
         ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
         self._chk(self.L.uvaia_gpu_scan_stats(self.ctx, C.byref(ms), C.byref(n), C.byref(b), int(reset)))
         return ms.value, n.value, b.value
+
+    def replay_stats(self, reset=False):
+        """(admissions, on-demand evaluations, dense rescans) since the last reset."""
+        out = (C.c_ulonglong * 3)()
+        self._chk(self.L.uvaia_gpu_replay_stats(self.ctx, out, int(reset)))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def set_query_tile(self, qt):
         self._chk(self.L.uvaia_gpu_set_query_tile(self.ctx, int(qt)))

@@ -44,6 +44,8 @@ static __device__ __forceinline__ int bcnt_acc(uint32_t x, int acc)
 namespace {
 
 constexpr int HEAP_ENTRY = 8;          // 6 scores + 64-bit ordinal (lo, hi)
+constexpr int AMB_CAP = 11;            // alignment words with a partially ambiguous site remembered per sequence
+constexpr int AMB_STRIDE = AMB_CAP + 1;  // ints per sequence: count (uncapped) + word indices
 constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
 
 thread_local std::string g_open_error;
@@ -59,7 +61,14 @@ struct uvaia_gpu_ctx {
   size_t trim = 0;
   size_t max_pool = 0, pool_pad = 0;
   // query side
-  uint32_t *d_qp = nullptr;      // [nq_pad][W4][4][NQ]
+  uint32_t *d_qp = nullptr;      // [nq_pad][W4][4][NQ]   full-information query planes
+  uint32_t *d_qp2 = nullptr;     // [nq_pad][W4][4][4]    (lo, hi, isACGT, valid) for the two-counter scan (default mode)
+  int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
+  int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
+  int2 *d_cnt2 = nullptr;        // [nq_pad][pool_pad] two-counter scan output
+  unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
+  bool fullscan = false;         // UVAIA_GPU_FULLSCAN=1: four-counter scan + replay over it (kept for A/B and tests)
+  size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
   uint32_t *d_cpm = nullptr;     // consensus restricted to idx_m (radius search)
   uint32_t *d_qpoly = nullptr;   // queries restricted to idx (radius search), [nq_pad][W4][4][NQ]
@@ -81,7 +90,8 @@ struct uvaia_gpu_ctx {
   int *d_db_nonn = nullptr;
   size_t db_cap = 0, db_n = 0;
   // last batch (introspection)
-  const uint4 *last_tiles = nullptr; const int *last_nonn = nullptr; int last_n = 0, last_rbegin = 0, last_ppad = 0;
+  const uint4 *last_tiles = nullptr; const int *last_nonn = nullptr; int last_n = 0, last_rbegin = 0, last_ppad = 0, last_ntiles = 0;
+  long long last_tile_first = 0;
   // stats
   std::vector<ScanEvt> evts;
   double scan_ms = 0, scan_bytes = 0; long long scan_launches = 0;
@@ -123,14 +133,20 @@ __constant__ uint8_t c_code[256];
 // One block per tile of 64 database slots; wave v handles word groups w4 = v, v+4, ...  Slots outside
 // [slot0, slot0+n_ref) are left untouched (the database is zero-initialised), so appends need not be tile-aligned.
 // non_n_out (nullable): valid-site count over the FULL length (src/fastaseq.c:642-648).
+// amb_out (nullable): per slot AMB_STRIDE ints = number of alignment words holding a partially ambiguous (valid,
+// non-ACGT) site, then up to AMB_CAP of their indices; a count above AMB_CAP means "list incomplete, rescan densely".
 template <int P>
 __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restrict__ chars, size_t pitch, int nchar,
                                                          long long slot0, int n_ref, int W4, uint4 *__restrict__ tiles,
-                                                         long long tile_base, int *__restrict__ non_n_out, int *__restrict__ errflag)
+                                                         long long tile_base, int *__restrict__ non_n_out, int *__restrict__ amb_out,
+                                                         int *__restrict__ errflag)
 {
   __shared__ uint8_t lut[256];
   __shared__ int partial[4][64];
+  __shared__ int amb_n[64];
+  __shared__ int amb_w[64][AMB_CAP];
   lut[threadIdx.x] = c_code[threadIdx.x];
+  if (threadIdx.x < 64) amb_n[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long tile = tile_base + blockIdx.x;
@@ -157,12 +173,13 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
         } else {
           for (int s = 0; s < 32; s++) b[s] = (site0 + s < nchar) ? row[site0 + s] : (uint8_t)'N';
         }
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, partial_code = 0;
 #pragma unroll
         for (int s = 0; s < 32; s++) {
           uint32_t code = (site0 + s < nchar) ? lut[b[s]] : 0u;
           if (code == 0xFFu) { bad = 1; code = 0; }
           valid += (code != 0);
+          partial_code |= code & (code - 1);
           if (P == 4) {
             a0 |= (code & 1u) << s; a1 |= ((code >> 1) & 1u) << s; a2 |= ((code >> 2) & 1u) << s; a3 |= ((code >> 3) & 1u) << s;
           } else {  // 2-bit code + "is ACGT" plane: A=0 C=1 G=2 T=3
@@ -172,6 +189,7 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
           }
         }
         pl[0][j] = a0; pl[1][j] = a1; pl[2][j] = a2; pl[3][j] = a3;
+        if (partial_code) { const int pos = atomicAdd(&amb_n[lane], 1); if (pos < AMB_CAP) amb_w[lane][pos] = w4 * 4 + j; }
       }
       uint4 *dst = tiles + ((size_t)(tile * W4 + w4) * P) * 64 + lane;
 #pragma unroll
@@ -181,6 +199,11 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
   partial[wv][lane] = valid;
   __syncthreads();
   if (wv == 0 && active && non_n_out) non_n_out[slot] = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+  if (wv == 0 && active && amb_out) {
+    int *a = amb_out + (size_t)slot * AMB_STRIDE;
+    a[0] = amb_n[lane];
+    for (int k = 0; k < AMB_CAP; k++) a[1 + k] = (k < amb_n[lane]) ? amb_w[lane][k] : 0;
+  }
   if (bad) atomicOr(errflag, 1);
 }
 
@@ -294,6 +317,108 @@ __global__ __launch_bounds__(256) void scan_acgt_kernel(const uint4 *__restrict_
   const size_t r = (size_t)trel * 64 + lane;
 #pragma unroll
   for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int4(acc[q][0], acc[q][1], acc[q][2], 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: the two-counter pair scan (production path)
+// ------------------------------------------------------------------------------------------------------------
+// The gate of src/nearest.c:488-496 only needs the mismatch count m = valid - ACGT_matches of a pair, and the heap
+// order is decided by ACGT_matches first (src/min_heap.c:41-47).  The dense pass therefore counts just
+//   default: r0 = #(equal & ACGT), r3 = #(both valid)          --acgt: c0 = #(both ACGT & differ), c1 = #(both ACGT)
+// and the replay kernel fetches the remaining counters of the few pairs that reach the heap (below).
+// Reference words are re-coded per word into (lo, hi, isACGT, valid); query planes arrive in that coding.
+// 4 logic ops + 2 v_bcnt per pair-word.
+template <int QT>
+__global__ __launch_bounds__(256) void scan2_iupac_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
+                                                           const uint32_t *__restrict__ qp2, int2 *__restrict__ out, int ppad)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int trel = blockIdx.y * 4 + wave;
+  if (trel >= n_tiles) return;
+  const int q0 = blockIdx.x * QT;
+  int acc[QT][2];
+#pragma unroll
+  for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = 0; }
+  const uint4 *t = db + (size_t)(tile_first + trel) * W4 * 4 * 64 + lane;
+  const size_t qstride = (size_t)W4 * 16;
+  const uint32_t *qb = qp2 + (size_t)q0 * qstride;
+  for (int w4 = 0; w4 < W4; w4++) {
+    const uint4 pA = t[(size_t)(w4 * 4 + 0) * 64], pC = t[(size_t)(w4 * 4 + 1) * 64], pG = t[(size_t)(w4 * 4 + 2) * 64], pT = t[(size_t)(w4 * 4 + 3) * 64];
+    const uint32_t rA[4] = {pA.x, pA.y, pA.z, pA.w}, rC[4] = {pC.x, pC.y, pC.z, pC.w}, rG[4] = {pG.x, pG.y, pG.z, pG.w}, rT[4] = {pT.x, pT.y, pT.z, pT.w};
+    uint32_t rL[4], rH[4], rI[4], rV[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t par = B3(rA[j], rC[j], rG[j], TT_A ^ TT_B ^ TT_C) ^ rT[j];                 // odd number of set planes
+      const uint32_t ac = rA[j] & rC[j], gt = rG[j] & rT[j];
+      const uint32_t three = B3(ac, rG[j], rT[j], TT_A & (TT_B | TT_C)) | B3(gt, rA[j], rC[j], TT_A & (TT_B | TT_C));
+      rI[j] = par & ~three;                                                                      // exactly one plane set
+      rL[j] = B3(rC[j], rT[j], rI[j], (TT_A | TT_B) & TT_C);                                     // A=0 C=1 G=2 T=3
+      rH[j] = B3(rG[j], rT[j], rI[j], (TT_A | TT_B) & TT_C);
+      rV[j] = B3(rA[j], rC[j], rG[j], TT_A | TT_B | TT_C) | rT[j];
+    }
+    const uint32_t *s0 = qb + (size_t)w4 * 16;
+    QWords<16> cur, nxt;
+    load_qwords(cur, s0);
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t qL = cur.v[j * 4 + 0], qH = cur.v[j * 4 + 1], qI = cur.v[j * 4 + 2], qV = cur.v[j * 4 + 3];
+        const uint32_t d = rL[j] ^ qL;
+        const uint32_t y = B3(rH[j], qH, d, (TT_A ^ TT_B) | TT_C);
+        acc[q][0] = bcnt_acc(B3(y, rI[j], qI, ~TT_A & TT_B & TT_C), acc[q][0]);
+        acc[q][1] = bcnt_acc(rV[j] & qV, acc[q][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < QT) cur = nxt;
+    }
+  }
+  const size_t r = (size_t)trel * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], acc[q][1]);
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
+                                                          const uint32_t *__restrict__ qp, int2 *__restrict__ out, int ppad)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int trel = blockIdx.y * 4 + wave;
+  if (trel >= n_tiles) return;
+  const int q0 = blockIdx.x * QT;
+  int acc[QT][2];
+#pragma unroll
+  for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = 0; }
+  const uint4 *t = db + (size_t)(tile_first + trel) * W4 * 3 * 64 + lane;
+  const size_t qstride = (size_t)W4 * 16;
+  const uint32_t *qb = qp + (size_t)q0 * qstride;
+  for (int w4 = 0; w4 < W4; w4++) {
+    const uint4 pL = t[(size_t)(w4 * 3 + 0) * 64], pH = t[(size_t)(w4 * 3 + 1) * 64], pI = t[(size_t)(w4 * 3 + 2) * 64];
+    const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
+    const uint32_t *s0 = qb + (size_t)w4 * 16;
+    QWords<16> cur, nxt;
+    load_qwords(cur, s0);
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t qL = cur.v[j * 4 + 0], qH = cur.v[j * 4 + 1], qI = cur.v[j * 4 + 2];
+        const uint32_t d = rL[j] ^ qL;
+        const uint32_t y = B3(rH[j], qH, d, (TT_A ^ TT_B) | TT_C);
+        acc[q][0] = bcnt_acc(B3(y, rI[j], qI, TT_A & TT_B & TT_C), acc[q][0]);
+        acc[q][1] = bcnt_acc(rI[j] & qI, acc[q][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < QT) cur = nxt;
+    }
+  }
+  const size_t r = (size_t)trel * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], acc[q][1]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -518,6 +643,193 @@ __global__ __launch_bounds__(64) void replay_kernel(const int4 *__restrict__ cnt
   }
 }
 
+// ---- on-demand counters for the pairs that reach the heap -------------------------------------------------------
+static __device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// contribution of one alignment word to  d1 = #(equal & valid & not ACGT)  and  d2 = #(sets intersect & not equal)
+static __device__ __forceinline__ void iupac_word_extra(const uint32_t *__restrict__ dbw, size_t tile_abs, int lane_r, int W4, const uint32_t *__restrict__ qrow6,
+                                                        int w, int &d1, int &d2)
+{
+  const size_t base = (((size_t)tile_abs * W4 + (w >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (w & 3);   // u32 index of plane 0
+  const uint32_t rA = dbw[base], rC = dbw[base + 256], rG = dbw[base + 512], rT = dbw[base + 768];
+  const uint32_t *s = qrow6 + (size_t)w * 6;
+  const uint32_t qA = s[0], qC = s[1], qG = s[2], qT_ = s[3], qa = s[5];
+  const uint32_t rv = rA | rC | rG | rT;
+  const uint32_t nd = ~((rA ^ qA) | (rC ^ qC) | (rG ^ qG) | (rT ^ qT_));
+  const uint32_t e = nd & rv, a0 = nd & qa, x = (rA & qA) | (rC & qC) | (rG & qG) | (rT & qT_);
+  d1 += __popc(e & ~a0);
+  d2 += __popc(x & ~e);
+}
+
+// Default mode: text_matches - ACGT_matches and partial_matches - text_matches of one pair.  Both differences live on
+// sites where the query or the reference carries a partially ambiguous code, so only the alignment words listed for
+// either sequence are visited (all words if a list overflowed).  Whole wave cooperates; result in every lane.
+static __device__ int2 wave_iupac_extra(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *__restrict__ qrow6,
+                                        const int *__restrict__ amb_r, const int *__restrict__ amb_q, int lane, bool &dense)
+{
+  const uint32_t *dbw = reinterpret_cast<const uint32_t *>(db);
+  const int nr = amb_r[0], nq = amb_q[0];
+  int d1 = 0, d2 = 0;
+  dense = (nr > AMB_CAP || nq > AMB_CAP);
+  if (!dense) {
+    int w = -1;
+    if (lane < nq) w = amb_q[1 + lane];
+    else if (lane < nq + nr) {
+      w = amb_r[1 + lane - nq];
+      for (int k = 0; k < nq; k++) if (amb_q[1 + k] == w) w = -1;     // already covered by the query's list
+    }
+    if (w >= 0) iupac_word_extra(dbw, tile_abs, lane_r, W4, qrow6, w, d1, d2);
+  } else {
+    for (int w = lane; w < W4 * 4; w += 64) iupac_word_extra(dbw, tile_abs, lane_r, W4, qrow6, w, d1, d2);
+  }
+  return make_int2(wave_sum(d1), wave_sum(d2));
+}
+
+// --acgt mode: mismatches on the polymorphic query columns (score[5], src/nearest.c:469) of one pair, dense.
+static __device__ int wave_acgt_poly_mismatches(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *__restrict__ qrow4, int lane)
+{
+  int mp = 0;
+  for (int w4 = lane; w4 < W4; w4 += 64) {
+    const uint4 *t = db + ((size_t)tile_abs * W4 + w4) * 3 * 64 + lane_r;
+    const uint4 pL = t[0], pH = t[64], pI = t[128];
+    const uint32_t *s = qrow4 + (size_t)w4 * 16;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t y = ((&pL.x)[j] ^ s[j * 4 + 0]) | ((&pH.x)[j] ^ s[j * 4 + 1]);
+      mp += __popc(y & (&pI.x)[j] & s[j * 4 + 3]);
+    }
+  }
+  return wave_sum(mp);
+}
+
+// Replay over the two-counter scan.  One wave per query walks the batch in reference order, 256 references per
+// round.  Between two admissions the heap state is constant, so the exact tests of src/nearest.c:488-496 and
+// src/min_heap.c:95 are evaluated for 64 references at once (ballot); the first survivor in order gets its missing
+// counters on demand, is compared exactly, and if admitted the remaining lanes are re-tested against the new state.
+template <bool ACGT>
+__global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cnt, int ppad, const int4 *__restrict__ rt, const int4 *__restrict__ tr,
+                                                      const int *__restrict__ nonn, const int *__restrict__ amb, int r_begin, int r_end, long long ord_base,
+                                                      int *__restrict__ heap_g, int *__restrict__ n_g, int *__restrict__ T_g,
+                                                      const int *__restrict__ snap_ptr, uint8_t *__restrict__ entered, int k,
+                                                      const uint4 *__restrict__ db, long long tile_first, int W4,
+                                                      const uint32_t *__restrict__ qfull, const int *__restrict__ amb_q,
+                                                      unsigned long long *__restrict__ stats)
+{
+  extern __shared__ int h[];
+  constexpr int U = 4;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
+  int n = n_g[q], T = T_g[q];
+  const int snap = *snap_ptr;
+  for (int i = lane; i < (n + 1) * HEAP_ENTRY; i += 64) h[i] = hg[i];
+  __syncthreads();
+  bool full = (n == k);
+  int W[6] = {0, 0, 0, 0, 0, 0};
+  if (full) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) W[i] = h[HEAP_ENTRY + i];
+  }
+  const int2 *crow = cnt + (size_t)q * ppad;
+  const uint32_t *qrow = qfull + (size_t)q * W4 * 4 * (ACGT ? 4 : 6);
+  const int *aq = amb_q + (size_t)q * AMB_STRIDE;
+  bool dirty = false;
+  unsigned n_admit = 0, n_demand = 0, n_dense = 0;
+  for (int base = r_begin; base < r_end; base += 64 * U) {
+    int2 c[U]; int4 a[U], rc[U]; int nn[U], m[U], K0[U], K1[U], K2[U], K3[U]; bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = base + u * 64 + lane;
+      valid[u] = r < r_end;
+      c[u] = make_int2(0, 0); a[u] = rc[u] = make_int4(0, 0, 0, 0); nn[u] = 0;
+      if (valid[u]) { c[u] = crow[r]; a[u] = rt[r]; rc[u] = tr[r]; nn[u] = nonn[r]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int mc_true = ACGT ? a[u].x : (a[u].w - a[u].x);
+      if (mc_true < snap) rc[u] = a[u];                   // cq->res was not cut short (src/nearest.c:431-432)
+      if (ACGT) {       // keys 0..3 are known from the two counters: matches, valid, unique matches, valid ref sites
+        K1[u] = c[u].y - a[u].y + rc[u].y;
+        K0[u] = K1[u] - (c[u].x - a[u].x + rc[u].x);
+        K2[u] = K0[u] - (rc[u].y - rc[u].x);
+        K3[u] = nn[u];
+        m[u] = K1[u] - K0[u];
+      } else {          // only key 0 (ACGT matches) and the pair's valid count are known
+        K0[u] = c[u].x - a[u].x + rc[u].x;
+        K3[u] = c[u].y - a[u].w + rc[u].w;
+        K1[u] = K2[u] = 0;
+        m[u] = K3[u] - K0[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      auto may_enter = [&]() -> bool {
+        if (!valid[u] || m[u] >= T) return false;
+        if (!full) return true;
+        if (ACGT) {
+          if (K0[u] != W[0]) return K0[u] > W[0];
+          if (K1[u] != W[1]) return K1[u] > W[1];
+          if (K2[u] != W[2]) return K2[u] > W[2];
+          return K3[u] >= W[3];
+        }
+        return K0[u] >= W[0];
+      };
+      unsigned long long mask = __ballot(may_enter());
+      while (mask) {
+        const int i = __ffsll((long long)mask) - 1;
+        const int rl = base + u * 64 + i;                                 // index relative to the first tile of the batch
+        const int cx = __shfl(c[u].x, i), cy = __shfl(c[u].y, i);
+        const int4 ai = make_int4(__shfl(a[u].x, i), __shfl(a[u].y, i), __shfl(a[u].z, i), __shfl(a[u].w, i));
+        const int4 ri = make_int4(__shfl(rc[u].x, i), __shfl(rc[u].y, i), __shfl(rc[u].z, i), __shfl(rc[u].w, i));
+        const int nni = __shfl(nn[u], i);
+        const size_t tile_abs = (size_t)tile_first + (size_t)(rl >> 6);
+        int Si[6], mi;
+        n_demand++;
+        if (ACGT) {
+          const int mp = wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
+          assemble_scores<true>(make_int4(cx, cy, mp, 0), ai, ri, nni, Si, mi);
+        } else {
+          bool dense;
+          const int2 d = wave_iupac_extra(db, tile_abs, rl & 63, W4, qrow, amb + (size_t)rl * AMB_STRIDE, aq, lane, dense);
+          n_dense += dense;
+          assemble_scores<false>(make_int4(cx, cx + d.x, cx + d.x + d.y, cy), ai, ri, nni, Si, mi);
+        }
+        const bool accept = (mi < T) && (!full || lex_better(Si, W));     // src/nearest.c:488-496 + heap_insert :93-117
+        if (!accept) { mask &= mask - 1; continue; }
+        if (lane == 0) {
+          const long long ord = ord_base + (rl - r_begin);
+          int *e = h + (full ? 1 : n + 1) * HEAP_ENTRY;
+#pragma unroll
+          for (int s = 0; s < 6; s++) e[s] = Si[s];
+          e[6] = (int)(unsigned)(ord & 0xffffffffll); e[7] = (int)(ord >> 32);
+          if (full) heap_sift_down(h, n, 1); else heap_sift_up(h, n + 1);
+          entered[rl] = 1;
+        }
+        if (!full) n++;
+        dirty = true; n_admit++;
+        __syncthreads();
+        full = (n == k);
+        if (full) {
+#pragma unroll
+          for (int s = 0; s < 6; s++) W[s] = h[HEAP_ENTRY + s];
+          T = entry_mismatches<ACGT>(W) + 1;                               // src/nearest.c:506-508 / :474-475
+        }
+        mask = __ballot(lane > i && may_enter());
+      }
+    }
+  }
+  if (dirty) {
+    __syncthreads();
+    for (int i = lane; i < (n + 1) * HEAP_ENTRY; i += 64) hg[i] = h[i];
+    if (lane == 0) { n_g[q] = n; T_g[q] = T; }
+  }
+  if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)n_admit); atomicAdd(&stats[1], (unsigned long long)n_demand); atomicAdd(&stats[2], (unsigned long long)n_dense); }
+}
+
 __global__ void snapshot_kernel(const int *__restrict__ T, int nq, int *__restrict__ snap)
 { // cq->max_incompatible = max over heaps (src/nearest.c:290-291)
   __shared__ int red[256];
@@ -598,6 +910,34 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
   return 0;
 }
 
+int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes)
+{
+  if (n_tiles <= 0) return 0;
+  dim3 grid((unsigned)(c->nq_pad / c->qt), (unsigned)((n_tiles + 3) / 4)), block(256);
+  ScanEvt ev{};
+  if (c->profile) {
+    HIPCHK(c, hipEventCreate(&ev.a)); HIPCHK(c, hipEventCreate(&ev.b));
+    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+  }
+  const uint32_t *qp = c->acgt ? c->d_qp : c->d_qp2;
+#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, c->stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad)
+  if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan2_acgt_kernel, 8); break; case 32: LAUNCH(scan2_acgt_kernel, 32); break; default: LAUNCH(scan2_acgt_kernel, 16); } }
+  else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
+#undef LAUNCH
+  HIPCHK(c, hipGetLastError());
+  if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, c->stream)); ev.bytes = bytes; c->evts.push_back(ev); }
+  return 0;
+}
+
+int ensure_cnt4(uvaia_gpu_ctx *c, size_t elems)
+{
+  if (c->cnt_cap >= elems) return 0;
+  if (c->d_cnt) { HIPCHK(c, hipFree(c->d_cnt)); c->d_cnt = nullptr; c->cnt_cap = 0; }
+  HIPCHK(c, hipMalloc(&c->d_cnt, elems * sizeof(int4)));
+  c->cnt_cap = elems;
+  return 0;
+}
+
 int collect_events(uvaia_gpu_ctx *c)
 {
   for (auto &e : c->evts) {
@@ -612,7 +952,7 @@ int collect_events(uvaia_gpu_ctx *c)
 
 // One batch = one pool of the reference (src/nearest.c:288-306), on tiles [tile_first, tile_first+n_tiles) of `tiles`;
 // references r_begin..r_end-1 (relative to the first tile) are the batch, in order.
-int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, long long tile_first, int n_tiles, int r_begin, int r_end,
+int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const int *amb_tile0, long long tile_first, int n_tiles, int r_begin, int r_end,
               long long ord_base, uint8_t *entered_tile0)
 {
   if (r_end <= r_begin) {   // an empty trailing batch only refreshes cq->max_incompatible (src/nearest.c:290-291)
@@ -624,19 +964,30 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, long 
   else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
   HIPCHK(c, hipGetLastError());
   const double bytes = (double)(r_end - r_begin) * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  int rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq_pad, c->d_cnt, ppad, bytes);
-  if (rc) return rc;
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
-  if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
-  else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
+  if (c->fullscan) {
+    int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
+    rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq_pad, c->d_cnt, ppad, bytes);
+    if (rc) return rc;
+    if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
+    else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
+  } else {
+    int rc = launch_scan2(c, tiles, tile_first, n_tiles, c->d_cnt2, ppad, bytes);
+    if (rc) return rc;
+    if (c->acgt) hipLaunchKernelGGL((replay2_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base,
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
+    else         hipLaunchKernelGGL((replay2_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base,
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
+  }
   HIPCHK(c, hipGetLastError());
   c->last_tiles = tiles; c->last_nonn = nonn_tile0; c->last_n = r_end - r_begin; c->last_rbegin = r_begin; c->last_ppad = ppad;
+  c->last_ntiles = n_tiles; c->last_tile_first = tile_first;
   return 0;
 }
 
 // stage + pack n_ref rows (either scattered pointers or one pitched block) into `tiles` starting at slot0
 int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t rows_pitch, const int *non_n, int n_ref,
-              uint4 *tiles, int *nonn_dev, long long slot0)
+              uint4 *tiles, int *nonn_dev, int *amb_dev, long long slot0)
 {
   for (int done = 0; done < n_ref; done += PACK_CHUNK) {
     const int m = std::min(PACK_CHUNK, n_ref - done);
@@ -649,8 +1000,8 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
     const long long s0 = slot0 + done, t0 = s0 / 64, t1 = (s0 + m - 1) / 64;
     const int nblk = (int)(t1 - t0 + 1);
     int *nn_out = non_n ? nullptr : nonn_dev;
-    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, c->d_err);
-    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, c->d_err);
+    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, (int *)nullptr, c->d_err);
+    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, amb_dev, c->d_err);
     HIPCHK(c, hipGetLastError());
     if (non_n) HIPCHK(c, hipMemcpyAsync(nonn_dev + s0, non_n + done, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // h_stage is reused by the next round
@@ -675,7 +1026,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+  void *dev[] = {c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -705,6 +1056,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   c->qt = 16;
   const char *env_qt = getenv("UVAIA_GPU_QT");
   if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
+  const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
+  c->fullscan = env_full && atoi(env_full) != 0;
   c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
   c->max_pool = max_pool; c->pool_pad = ((max_pool + 63) / 64) * 64 + 64;
   c->pitch = ((size_t)c->nchar + 63) / 64 * 64;
@@ -736,6 +1089,22 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EALPHABET, "consensus holds byte 0x%02x outside the supported alphabet", bad);
   }
   OPENCHK(hipMalloc(&c->d_qp, qp.size() * 4)); OPENCHK(hipMemcpy(c->d_qp, qp.data(), qp.size() * 4, hipMemcpyHostToDevice));
+  {  // recoded planes and ambiguity-word lists for the two-counter path
+    std::vector<int> ambq((size_t)c->nq * AMB_STRIDE, 0);
+    if (!c->acgt) {
+      const size_t row2 = (size_t)c->W4 * 16;
+      std::vector<uint32_t> qp2((size_t)c->nq_pad * row2, 0u);
+      for (int i = 0; i < c->nq; i++) for (int w = 0; w < c->W4 * 4; w++) {
+        const uint32_t *s6 = qp.data() + (size_t)i * row_words + (size_t)w * 6;
+        uint32_t *d4 = qp2.data() + (size_t)i * row2 + (size_t)w * 4;
+        const uint32_t one = s6[5];
+        d4[0] = (s6[1] | s6[3]) & one; d4[1] = (s6[2] | s6[3]) & one; d4[2] = one; d4[3] = s6[4];
+        if (s6[4] & ~one) { int &cnt = ambq[(size_t)i * AMB_STRIDE]; if (cnt < AMB_CAP) ambq[(size_t)i * AMB_STRIDE + 1 + cnt] = w; cnt++; }
+      }
+      OPENCHK(hipMalloc(&c->d_qp2, qp2.size() * 4)); OPENCHK(hipMemcpy(c->d_qp2, qp2.data(), qp2.size() * 4, hipMemcpyHostToDevice));
+    }
+    OPENCHK(hipMalloc(&c->d_amb_q, ambq.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_amb_q, ambq.data(), ambq.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   OPENCHK(hipMalloc(&c->d_qpoly, qpoly.size() * 4)); OPENCHK(hipMemcpy(c->d_qpoly, qpoly.data(), qpoly.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cp, cp.size() * 4)); OPENCHK(hipMemcpy(c->d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cpm, cpm.size() * 4)); OPENCHK(hipMemcpy(c->d_cpm, cpm.data(), cpm.size() * 4, hipMemcpyHostToDevice));
@@ -753,7 +1122,11 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_batch, 0, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
   OPENCHK(hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMalloc(&c->d_cnt, (size_t)c->nq_pad * c->pool_pad * sizeof(int4)));
+  OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_STRIDE * sizeof(int)));
+  OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_STRIDE * sizeof(int)));
+  if (!c->fullscan) OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  OPENCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
+  OPENCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMalloc(&c->d_rt, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_tr, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_entered, c->pool_pad)); c->entered_cap = c->pool_pad;
@@ -801,11 +1174,11 @@ int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, i
   if (n_ref < 0 || (n_ref > 0 && !seq)) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
   if (n_ref == 0) return 0;
-  int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, 0);
+  int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, 0);
   if (rc) return rc;
   const int n_tiles = (n_ref + 63) / 64;
   HIPCHK(c, hipMemsetAsync(c->d_entered, 0, (size_t)n_tiles * 64, c->stream));
-  rc = run_batch(c, c->d_batch, c->d_batch_nonn, 0, n_tiles, 0, n_ref, ordinal0, c->d_entered);
+  rc = run_batch(c, c->d_batch, c->d_batch_nonn, c->d_batch_amb, 0, n_tiles, 0, n_ref, ordinal0, c->d_entered);
   if (rc) return rc;
   if (entered) HIPCHK(c, hipMemcpyAsync(entered, c->d_entered, (size_t)n_ref, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -834,12 +1207,14 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   if (!c) return UVAIA_GPU_EINVAL;
   if (cap <= c->db_cap) return 0;
   if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "reserve the database before appending to it");
-  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); c->d_db = nullptr; c->d_db_nonn = nullptr; }
+  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); c->d_db = nullptr; c->d_db_nonn = nullptr; c->d_db_amb = nullptr; }
   const size_t tiles = (cap + 63) / 64 + 1, tile_u4 = (size_t)c->W4 * c->P * 64;
   HIPCHK(c, hipMalloc(&c->d_db, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMemset(c->d_db, 0, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_nonn, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_db_amb, tiles * 64 * AMB_STRIDE * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_db_amb, 0, tiles * 64 * AMB_STRIDE * sizeof(int)));
   c->db_cap = tiles * 64 - 64;
   if (c->entered_cap < tiles * 64) {
     hipFree(c->d_entered); c->d_entered = nullptr;
@@ -857,7 +1232,7 @@ static int db_append_common(uvaia_gpu_ctx *c, const char *const *seq, const char
     if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "database capacity %zu exceeded: call uvaia_gpu_db_reserve first", c->db_cap);
     int rc = uvaia_gpu_db_reserve(c, (size_t)n_ref); if (rc) return rc;
   }
-  int rc = pack_rows(c, seq, rows, pitch, non_n, n_ref, c->d_db, c->d_db_nonn, (long long)c->db_n);
+  int rc = pack_rows(c, seq, rows, pitch, non_n, n_ref, c->d_db, c->d_db_nonn, c->d_db_amb, (long long)c->db_n);
   if (rc) return rc;
   c->db_n += (size_t)n_ref;
   return 0;
@@ -885,7 +1260,7 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
     const long long tf = (long long)(a / 64);
     const int n_tiles = (int)((b + 63) / 64 - a / 64);
     const int rb = (int)(a - (size_t)tf * 64), re = (int)(b - (size_t)tf * 64);
-    int rc = run_batch(c, c->d_db, c->d_db_nonn + tf * 64, tf, n_tiles, rb, re, ordinal0 + (long long)a - rb + rb, c->d_entered + tf * 64);
+    int rc = run_batch(c, c->d_db, c->d_db_nonn + tf * 64, c->d_db_amb + tf * 64 * AMB_STRIDE, tf, n_tiles, rb, re, ordinal0 + (long long)a, c->d_entered + tf * 64);
     if (rc) return rc;
   }
   if (entered) {
@@ -909,6 +1284,13 @@ int uvaia_gpu_last_batch_scores(uvaia_gpu_ctx *c, int *out, int n_ref)
   if (n_ref != c->last_n || !c->last_nonn) return fail(c, UVAIA_GPU_ESTATE, "last batch held %d references, not %d", c->last_n, n_ref);
   int *d_out = nullptr;
   const size_t bytes = (size_t)n_ref * c->nq * 6 * sizeof(int);
+  if (!c->fullscan) {   // the production path keeps two counters per pair: recount the batch with the four-counter kernel
+    int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->last_ppad); if (rc) return rc;
+    const bool prof = c->profile; c->profile = false;
+    rc = launch_scan(c, c->last_tiles, c->last_tile_first, c->last_ntiles, c->d_qp, c->nq_pad, c->d_cnt, c->last_ppad, 0.0);
+    c->profile = prof;
+    if (rc) return rc;
+  }
   HIPCHK(c, hipMalloc(&d_out, bytes));
   dim3 grid((n_ref + 255) / 256, c->nq);
   if (c->acgt) hipLaunchKernelGGL((batch_scores_kernel<true>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->d_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
@@ -929,6 +1311,17 @@ int uvaia_gpu_scan_stats(uvaia_gpu_ctx *c, double *ms, long long *launches, doub
   if (launches) *launches = c->scan_launches;
   if (bytes) *bytes = c->scan_bytes;
   if (reset) { c->scan_ms = 0; c->scan_bytes = 0; c->scan_launches = 0; }
+  return 0;
+}
+
+int uvaia_gpu_replay_stats(uvaia_gpu_ctx *c, unsigned long long out[3], int reset)
+{
+  if (!c || !out) return UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+  if (reset) HIPCHK(c, hipMemset(c->d_stats, 0, sizeof h));
   return 0;
 }
 

@@ -59,11 +59,17 @@ def main():
             print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # UVAIA_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (state blobs via host memory)
+    backend = os.environ.get("UVAIA_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
@@ -81,19 +87,29 @@ def main():
         eng.set_query_tile(args.qt)
     eng.db_reserve(args.refs)
     t0 = time.time()
-    first = rank * args.refs                      # this rank's shard of the stream
+    from uvaia_amd import ring
+    # block-cyclic shard: stripe s (= one pool of world*pool references of the stream) = slice s of rank 0, 1, ...
+    slices = ring.block_cyclic_layout(args.refs, pool, rank, world)
+    first = slices[0].ordinal0
     chunk = 8192
-    for a in range(0, args.refs, chunk):
-        n = min(chunk, args.refs - a)
-        rows, non_n = gen.generate(first + a, n)
-        eng.db_append_block(rows, non_n)
+    for sl in slices:
+        for a in range(0, sl.n, chunk):
+            n = min(chunk, sl.n - a)
+            rows, non_n = gen.generate(sl.ordinal0 + a, n)
+            eng.db_append_block(rows, non_n)
     load_s = time.time() - t0
     bytes_per_ref = eng.packed_bytes_per_ref()
+    on_gpu = backend == "nccl"
+    comm = ring.TorchComm(dist, cuda=on_gpu) if dist is not None else None
+    nbytes = eng.state_bytes()
 
     # ---- timed region
     def step():
         eng.reset()
-        eng.search_resident(pool, ordinal0=first, want_entered=False)
+        if world == 1:
+            eng.search_resident(pool, ordinal0=0, want_entered=False)
+        else:   # scans run concurrently on all ranks; the heap state visits the ranks in stream order over RCCL send/recv
+            ring.run_ring(eng, comm, rank, world, slices, lambda: ring.TorchStateBuffer(nbytes, "cuda" if on_gpu else "cpu"))
         eng.sync()
 
     for _ in range(args.warmup):
@@ -108,7 +124,7 @@ def main():
     scan_ms, scan_launches, scan_bytes = eng.scan_stats(reset=True)
     admitted, demanded, dense_rescans = eng.replay_stats(reset=True)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
@@ -168,6 +184,7 @@ def main():
             "metric": "ref-seqs scored/sec", "value": round(value, 2), "unit": "ref-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "multi_gpu": None if world == 1 else "block-cyclic slices of %d refs, concurrent scans, heap state (%d B) passed rank to rank per slice (RCCL send/recv), exact" % (pool, nbytes),
             "dtype": "u32 bit-planes / int32 counts", "data": "synthetic (seed %d, preset %d)" % (args.seed, args.preset),
             "config": {"workload": "BASELINE config[1]: %d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d"
                                    % (pq.ntax, args.refs, args.nchar, "4-bit IUPAC planes" if args.mode == "iupac" else "2-bit + validity planes (--acgt)", args.nbest, pool),

@@ -105,6 +105,22 @@ size_t uvaia_gpu_db_size (const uvaia_gpu_ctx *ctx);
 int uvaia_gpu_search_resident (uvaia_gpu_ctx *ctx, size_t pool, int64_t ordinal0, uint8_t *entered);
 int uvaia_gpu_sync (uvaia_gpu_ctx *ctx);
 
+/* ---- ring mode for several GPUs (one context per GPU/process; the caller moves the state blob between ranks, e.g. with
+ * RCCL send/recv).  A stripe = one batch of the reference (one pool) = the concatenation of one slice per rank, in rank
+ * order; every rank holds its slices in its resident database.  Per stripe, on every rank:
+ *     uvaia_gpu_slice_scan()                         (asynchronous; may be issued stripes ahead: two counter buffers)
+ *     [rank > 0 or not the first stripe]  receive blob from the previous rank in the ring; uvaia_gpu_state_import()
+ *     uvaia_gpu_slice_replay(stripe_start = (rank == 0))
+ *     uvaia_gpu_state_export(); send blob to the next rank
+ * The blob holds the batch snapshot of src/nearest.c:290-291 taken by rank 0, so truncation semantics are those of a
+ * single process running the same stripes as pools.  After the last stripe the last rank holds the final heaps. */
+size_t uvaia_gpu_state_bytes (const uvaia_gpu_ctx *ctx);
+int uvaia_gpu_state_export (uvaia_gpu_ctx *ctx, void *dst);          /* device or host pointer; returns when dst is complete */
+int uvaia_gpu_state_import (uvaia_gpu_ctx *ctx, const void *src);    /* ordered before later replays */
+int uvaia_gpu_slice_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, int buf);
+int uvaia_gpu_slice_replay (uvaia_gpu_ctx *ctx, int buf, int64_t ordinal0, int stripe_start);
+int uvaia_gpu_entered_flags (uvaia_gpu_ctx *ctx, uint8_t *out, int clear);   /* db_size bytes; see uvaia_gpu_search_resident */
+
 /* ---- radius search: replaces the loop of src/ball.c:248-251 (seq_ball_against_query_structure,
  * src/fastaseq.c:660-696) for one batch.  radius = cq->dist + 1.  mindist[i] receives what the reference leaves in
  * cq->mindist[c]; the caller keeps sequence i iff mindist[i] <= radius-1 (src/ball.c:255). */

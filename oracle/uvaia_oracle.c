@@ -408,6 +408,8 @@ struct orc_search {
   orc_heap **heap;
   int64_t n_seen, n_lowqual, n_samename, n_saved, cap_saved, *saved;
   int finished;
+  int snap_override;               /* >= 0: use this as cq->max_incompatible for the next batch (ring-protocol tests) */
+  int last_snapshot;
 };
 
 void orc_set_threads (int n)
@@ -448,6 +450,7 @@ orc_search_new (orc_query *q, int pool, int nbest, double ambig_r, int exclude_s
   s->heap    = (orc_heap **) calloc ((size_t) s->n_query, sizeof (orc_heap *));
   for (int i = 0; i < s->n_query; i++) { s->heap[i] = orc_heap_new (nbest); s->heap[i]->max_incompatible = s->max_incompatible; }
   s->cap_saved = 1024; s->saved = (int64_t *) malloc ((size_t) s->cap_saved * sizeof (int64_t));
+  s->snap_override = -1; s->last_snapshot = s->max_incompatible;
   return s;
 }
 
@@ -530,6 +533,8 @@ process_batch (orc_search *s)
   memset (s->is_best, 0, (size_t) s->pool * (size_t) s->n_query);
   s->max_incompatible = s->heap[0]->max_incompatible;
   for (j = 1; j < s->n_query; j++) if (s->max_incompatible < s->heap[j]->max_incompatible) s->max_incompatible = s->heap[j]->max_incompatible;
+  if (s->snap_override >= 0) { s->max_incompatible = s->snap_override; s->snap_override = -1; }
+  s->last_snapshot = s->max_incompatible;
 
 #pragma omp parallel for
   for (c = 0; c < s->fill; c++) consensus_score (s, c);
@@ -582,6 +587,70 @@ orc_search_finish (orc_search *s)
   process_batch (s);   /* also reproduces the empty trailing batch (only refreshes cq->max_incompatible) */
   for (int i = 0; i < s->n_query; i++) orc_heap_finalise (s->heap[i]);
   s->finished = 1;
+}
+
+/* ---- helpers for the multi-rank ring protocol tests (not reference functions) ----
+ * A stripe (= one pool of the reference) is cut into slices held by different ranks; each rank processes its slice as a
+ * batch of its own but with the stripe's snapshot of cq->max_incompatible, and hands the heap state to the next rank. */
+int
+orc_search_process_slice (orc_search *s, int n, const char *const *seqs, const char *const *names, const int64_t *ordinals, int snapshot)
+{
+  if (n > s->pool || s->fill) return -1;
+  for (int i = 0; i < n; i++) {
+    int c = s->fill++;
+    s->non_n[c] = orc_count_non_N (seqs[i], (size_t) s->q->nchar);
+    s->seq[c] = (char *) malloc ((size_t) s->q->nchar + 1); memcpy (s->seq[c], seqs[i], (size_t) s->q->nchar); s->seq[c][s->q->nchar] = '\0';
+    s->name[c] = strdup (names ? names[i] : "");
+    s->ordinal[c] = ordinals[i];
+  }
+  s->snap_override = snapshot;
+  process_batch (s);
+  return 0;
+}
+
+int orc_search_last_snapshot (const orc_search *s) { return s->last_snapshot; }
+
+size_t
+orc_search_state_ints (const orc_search *s)
+{
+  size_t per_q = 2 + (size_t) (s->heap[0]->heap_size + 1) * 8;
+  return 1 + per_q * (size_t) s->n_query;
+}
+
+void
+orc_search_get_state (const orc_search *s, int *blob)
+{
+  size_t per_q = 2 + (size_t) (s->heap[0]->heap_size + 1) * 8;
+  blob[0] = s->last_snapshot;
+  for (int q = 0; q < s->n_query; q++) {
+    int *b = blob + 1 + per_q * (size_t) q;
+    const orc_heap *h = s->heap[q];
+    b[0] = h->n; b[1] = h->max_incompatible;
+    for (int e = 0; e <= h->heap_size; e++) {
+      for (int k = 0; k < ORC_NSCORE; k++) b[2 + e * 8 + k] = h->seq[e].score[k];
+      b[2 + e * 8 + 6] = (int) (uint32_t) (h->seq[e].ordinal & 0xffffffffLL);
+      b[2 + e * 8 + 7] = (int) (h->seq[e].ordinal >> 32);
+    }
+  }
+}
+
+void
+orc_search_set_state (orc_search *s, const int *blob, const char *name_prefix)
+{
+  size_t per_q = 2 + (size_t) (s->heap[0]->heap_size + 1) * 8;
+  char buf[64];
+  s->last_snapshot = blob[0];
+  for (int q = 0; q < s->n_query; q++) {
+    const int *b = blob + 1 + per_q * (size_t) q;
+    orc_heap *h = s->heap[q];
+    h->n = b[0]; h->max_incompatible = b[1];
+    for (int e = 0; e <= h->heap_size; e++) {
+      for (int k = 0; k < ORC_NSCORE; k++) h->seq[e].score[k] = b[2 + e * 8 + k];
+      h->seq[e].ordinal = (int64_t) (((uint64_t) (uint32_t) b[2 + e * 8 + 7] << 32) | (uint32_t) b[2 + e * 8 + 6]);
+      free (h->seq[e].name); h->seq[e].name = NULL;
+      if (e >= 1 && e <= h->n) { snprintf (buf, sizeof buf, "%s%lld", name_prefix ? name_prefix : "", (long long) h->seq[e].ordinal); h->seq[e].name = strdup (buf); }
+    }
+  }
 }
 
 void

@@ -106,6 +106,12 @@ void orc_search_del (orc_search *s);
  * Sequences are nchar bytes, already upper-case.  Returns 0, or -1 on a length mismatch. */
 int  orc_search_feed (orc_search *s, int n, const char *const *seqs, const char *const *names, const int *lengths);
 void orc_search_end_of_file (orc_search *s);   /* boundary between two -r files */
+/* multi-rank ring protocol tests only: one slice of a stripe as a batch with the stripe's snapshot (<0: from own state) */
+int  orc_search_process_slice (orc_search *s, int n, const char *const *seqs, const char *const *names, const int64_t *ordinals, int snapshot);
+int  orc_search_last_snapshot (const orc_search *s);
+size_t orc_search_state_ints (const orc_search *s);
+void orc_search_get_state (const orc_search *s, int *blob);
+void orc_search_set_state (orc_search *s, const int *blob, const char *name_prefix);
 /* flush the last partial batch, sort heaps (src/nearest.c:343-344 -> :513-547) */
 void orc_search_finish (orc_search *s);
 /* results (valid after finish) */

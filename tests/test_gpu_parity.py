@@ -237,3 +237,46 @@ def test_four_counter_path_still_agrees(synth, acgt, monkeypatch):
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
     _assert_same_search(q, refs, 96, 9)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("world,slice_size,per_rank", [(2, 64, 256), (3, 50, 170)])
+def test_ring_mode_with_several_contexts_on_one_gpu(synth, acgt, world, slice_size, per_rank):
+    """Multi-GPU protocol (block-cyclic slices, state blob handed rank to rank) with one context per 'rank' on the same card;
+    must equal a single process running the same stream with pool = world x slice."""
+    from uvaia_amd import ring
+    refs, qs = synth
+    refs = refs[:world * per_rank]
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+    gold = O.search(q, refs, _names(len(refs)), pool=world * slice_size, nbest=9, ambig_r=1.0)
+    layouts = [ring.block_cyclic_layout(per_rank, slice_size, r, world) for r in range(world)]
+    engines = []
+    try:
+        for r in range(world):
+            e = capi.Engine.from_query(q, nbest=9, max_pool=slice_size)
+            local = []
+            for sl in layouts[r]:
+                local += refs[sl.ordinal0:sl.ordinal0 + sl.n]
+            e.db_reserve(len(local)); e.db_append(local)
+            engines.append(e)
+
+        class HostBlob:
+            def __init__(self, nbytes):
+                self.arr = np.zeros(nbytes, dtype=np.uint8); self.ptr = self.arr.ctypes.data
+        last = ring.run_ring_in_one_process(engines, layouts, lambda: HostBlob(engines[0].state_bytes()))
+        n, T, sc, od = last.drain()
+        rows = capi.finalise_heaps(n, sc, od)
+        for iq in range(q.ntax):
+            assert rows[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]]
+        assert list(T) == gold.final_T
+        entered = set()
+        for r in range(world):
+            flags = engines[r].entered_flags()
+            pos = 0
+            for sl in layouts[r]:
+                entered |= {sl.ordinal0 + i for i in np.nonzero(flags[pos:pos + sl.n])[0]}
+                pos += sl.n
+        assert sorted(entered) == list(gold.saved)
+    finally:
+        for e in engines:
+            e.close()

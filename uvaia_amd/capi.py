@@ -15,7 +15,9 @@ SYMBOLS = [
     "uvaia_gpu_open", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
     "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball",
-    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
+    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
+    "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
+    "uvaia_gpu_entered_flags", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
 ]
 
 
@@ -82,6 +84,12 @@ def load_library():
         "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
         "uvaia_gpu_scan_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]),
         "uvaia_gpu_replay_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.c_int]),
+        "uvaia_gpu_state_bytes": (C.c_size_t, [vp]),
+        "uvaia_gpu_state_export": (C.c_int, [vp, C.c_void_p]),
+        "uvaia_gpu_state_import": (C.c_int, [vp, C.c_void_p]),
+        "uvaia_gpu_slice_scan": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int]),
+        "uvaia_gpu_slice_replay": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int]),
+        "uvaia_gpu_entered_flags": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_int]),
         "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
     }
@@ -218,6 +226,27 @@ class Engine:
         ms, n, b = C.c_double(), C.c_longlong(), C.c_double()
         self._chk(self.L.uvaia_gpu_scan_stats(self.ctx, C.byref(ms), C.byref(n), C.byref(b), int(reset)))
         return ms.value, n.value, b.value
+
+    # ---- ring mode (several GPUs): see include/uvaia_gpu.h
+    def state_bytes(self):
+        return self.L.uvaia_gpu_state_bytes(self.ctx)
+
+    def state_export(self, ptr):
+        self._chk(self.L.uvaia_gpu_state_export(self.ctx, C.c_void_p(ptr)))
+
+    def state_import(self, ptr):
+        self._chk(self.L.uvaia_gpu_state_import(self.ctx, C.c_void_p(ptr)))
+
+    def slice_scan(self, first, n, buf):
+        self._chk(self.L.uvaia_gpu_slice_scan(self.ctx, int(first), int(n), int(buf)))
+
+    def slice_replay(self, buf, ordinal0, stripe_start):
+        self._chk(self.L.uvaia_gpu_slice_replay(self.ctx, int(buf), int(ordinal0), int(bool(stripe_start))))
+
+    def entered_flags(self, clear=False):
+        ent = np.zeros(self.db_size(), dtype=np.uint8)
+        self._chk(self.L.uvaia_gpu_entered_flags(self.ctx, ent.ctypes.data_as(C.POINTER(C.c_uint8)), int(clear)))
+        return ent
 
     def replay_stats(self, reset=False):
         """(admissions, on-demand evaluations, dense rescans) since the last reset."""

@@ -34,6 +34,11 @@
 #define TT_C 0xAAu
 #define B3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt) & 0xFFu)
 
+static __device__ __forceinline__ uint32_t u4c(const uint4 &v, int j)
+{ // component j of a uint4; folds to a register pick once j is a constant (no address is taken)
+  return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+}
+
 static __device__ __forceinline__ int bcnt_acc(uint32_t x, int acc)
 { // v_bcnt_u32_b32 d, x, acc : popcount with free accumulate (keeps one VALU op per count and word)
   int r;
@@ -57,12 +62,21 @@ struct ScanEvt { hipEvent_t a, b; double bytes; };
 struct uvaia_gpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
+  hipEvent_t scan_done[2] = {nullptr, nullptr}, replay_done[2] = {nullptr, nullptr};
+  bool replay_recorded[2] = {false, false};
+  int2 *d_cnt2b = nullptr;                // second counter buffer (ring mode, allocated on first use)
+  int slice_tiles[2] = {0, 0}, slice_rb[2] = {0, 0}, slice_re[2] = {0, 0};
+  long long slice_tf[2] = {0, 0};
   int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16;
   size_t trim = 0;
   size_t max_pool = 0, pool_pad = 0;
   // query side
   uint32_t *d_qp = nullptr;      // [nq_pad][W4][4][NQ]   full-information query planes
   uint32_t *d_qp2 = nullptr;     // [nq_pad][W4][4][4]    (lo, hi, isACGT, valid) for the two-counter scan (default mode)
+  uint4 *d_qv = nullptr;         // [nq_pad/16][W4pad][16][4]  the same planes laid out for LDS staging (scan2v_kernel)
+  int W4pad = 0;
+  int scan_variant = 1;          // 0 = scalar-operand scan2_*_kernel, 1 = LDS-broadcast scan2v_kernel (UVAIA_GPU_SCAN=sgpr|lds)
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int2 *d_cnt2 = nullptr;        // [nq_pad][pool_pad] two-counter scan output
@@ -419,6 +433,97 @@ __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict
   const size_t r = (size_t)trel * 64 + lane;
 #pragma unroll
   for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], acc[q][1]);
+}
+
+// LDS-broadcast variant of the two-counter scan.  Measured on MI355X (profiles/r01_valu_rate_microbench.txt): a VALU
+// op with an SGPR source issues at half rate, so here the query words are staged through LDS (one broadcast
+// ds_read_b128 per query word = its four planes in VGPRs) and every logic op has VGPR sources only.  Each wave owns
+// R tiles (R references per lane) so that one LDS read feeds R pair-words.
+template <int QT, int R, bool ACGT>
+__global__ __launch_bounds__(256) void scan2v_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4, int W4pad,
+                                                      const uint4 *__restrict__ qv, int2 *__restrict__ out, int ppad)
+{
+  constexpr int CHW = 8, P = ACGT ? 3 : 4, CHUNK = CHW * QT * 4, PER_THREAD = CHUNK / 256;
+  static_assert(CHUNK % 256 == 0, "staging assumes a multiple of the block size");
+  __shared__ uint4 lq[2][CHUNK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.y * 4 + wave) * R;
+  int acc[QT][R][2];
+#pragma unroll
+  for (int q = 0; q < QT; q++)
+#pragma unroll
+    for (int r = 0; r < R; r++) { acc[q][r][0] = acc[q][r][1] = 0; }
+  const uint4 *qsrc = qv + (size_t)blockIdx.x * W4pad * QT * 4;
+  const int nchunks = W4pad / CHW;
+  uint4 st[PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < PER_THREAD; k++) lq[0][threadIdx.x + k * 256] = qsrc[threadIdx.x + k * 256];
+  __syncthreads();
+  for (int c = 0; c < nchunks; c++) {
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int k = 0; k < PER_THREAD; k++) st[k] = qsrc[(size_t)(c + 1) * CHUNK + threadIdx.x + k * 256];
+    }
+    const uint4 *lc = lq[c & 1];
+    for (int w4l = 0; w4l < CHW; w4l++) {
+      const int w4 = c * CHW + w4l;
+      if (w4 >= W4) break;
+      uint32_t rL[R][4], rH[R][4], rI[R][4], rV[R][4];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        // waves past the last tile recount the last one (their results are not stored): keeps the loads unconditional
+        const int tr_ = (t0 + r) < n_tiles ? (t0 + r) : (n_tiles - 1);
+        const uint4 *t = db + (size_t)(tile_first + tr_) * W4 * P * 64 + lane;
+        const uint4 p0 = t[(size_t)(w4 * P + 0) * 64], p1 = t[(size_t)(w4 * P + 1) * 64], p2 = t[(size_t)(w4 * P + 2) * 64],
+                    p3 = t[(size_t)(w4 * P + (P - 1)) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (ACGT) { rL[r][j] = u4c(p0, j); rH[r][j] = u4c(p1, j); rI[r][j] = u4c(p2, j); rV[r][j] = rI[r][j]; }
+          else {
+            const uint32_t a = u4c(p0, j), cc = u4c(p1, j), g = u4c(p2, j), tt = u4c(p3, j);
+            const uint32_t par = B3(a, cc, g, TT_A ^ TT_B ^ TT_C) ^ tt;
+            const uint32_t three = B3(a & cc, g, tt, TT_A & (TT_B | TT_C)) | B3(g & tt, a, cc, TT_A & (TT_B | TT_C));
+            rI[r][j] = par & ~three;
+            rL[r][j] = B3(cc, tt, rI[r][j], (TT_A | TT_B) & TT_C);
+            rH[r][j] = B3(g, tt, rI[r][j], (TT_A | TT_B) & TT_C);
+            rV[r][j] = B3(a, cc, g, TT_A | TT_B | TT_C) | tt;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < QT; q++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint4 qq = lc[(w4l * QT + q) * 4 + j];       // wave-uniform address: LDS broadcast
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const uint32_t d = rL[r][j] ^ qq.x;
+            const uint32_t y = B3(rH[r][j], qq.y, d, (TT_A ^ TT_B) | TT_C);
+            if (ACGT) {
+              acc[q][r][0] = bcnt_acc(B3(y, rI[r][j], qq.z, TT_A & TT_B & TT_C), acc[q][r][0]);
+              acc[q][r][1] = bcnt_acc(rI[r][j] & qq.z, acc[q][r][1]);
+            } else {
+              acc[q][r][0] = bcnt_acc(B3(y, rI[r][j], qq.z, ~TT_A & TT_B & TT_C), acc[q][r][0]);
+              acc[q][r][1] = bcnt_acc(rV[r][j] & qq.w, acc[q][r][1]);
+            }
+          }
+        }
+      }
+    }
+    if (c + 1 < nchunks) {
+#pragma unroll
+      for (int k = 0; k < PER_THREAD; k++) lq[(c + 1) & 1][threadIdx.x + k * 256] = st[k];
+    }
+    __syncthreads();
+  }
+  const int q0 = blockIdx.x * QT;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (t0 + r >= n_tiles) continue;
+    const size_t ri = (size_t)(t0 + r) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + ri] = make_int2(acc[q][r][0], acc[q][r][1]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -910,22 +1015,32 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
   return 0;
 }
 
-int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes)
+int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream = nullptr)
 {
   if (n_tiles <= 0) return 0;
+  if (!stream) stream = c->stream;
   dim3 grid((unsigned)(c->nq_pad / c->qt), (unsigned)((n_tiles + 3) / 4)), block(256);
   ScanEvt ev{};
   if (c->profile) {
     HIPCHK(c, hipEventCreate(&ev.a)); HIPCHK(c, hipEventCreate(&ev.b));
-    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+    HIPCHK(c, hipEventRecord(ev.a, stream));
   }
   const uint32_t *qp = c->acgt ? c->d_qp : c->d_qp2;
-#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, c->stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad)
+  if (c->scan_variant == 1) {
+    constexpr int QTV = 16, RV = 2;
+    dim3 gridv((unsigned)(c->nq_pad / QTV), (unsigned)((n_tiles + 4 * RV - 1) / (4 * RV)));
+    if (c->acgt) hipLaunchKernelGGL((scan2v_kernel<QTV, RV, true>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad);
+    else         hipLaunchKernelGGL((scan2v_kernel<QTV, RV, false>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad);
+    HIPCHK(c, hipGetLastError());
+    if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, stream)); ev.bytes = bytes; c->evts.push_back(ev); }
+    return 0;
+  }
+#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad)
   if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan2_acgt_kernel, 8); break; case 32: LAUNCH(scan2_acgt_kernel, 32); break; default: LAUNCH(scan2_acgt_kernel, 16); } }
   else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
 #undef LAUNCH
   HIPCHK(c, hipGetLastError());
-  if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, c->stream)); ev.bytes = bytes; c->evts.push_back(ev); }
+  if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, stream)); ev.bytes = bytes; c->evts.push_back(ev); }
   return 0;
 }
 
@@ -1019,6 +1134,9 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
 
 extern "C" {
 
+int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf);
+int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start);
+
 const char *uvaia_gpu_last_error(const uvaia_gpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_error.c_str(); }
 
 void uvaia_gpu_close(uvaia_gpu_ctx *c)
@@ -1026,10 +1144,13 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+  void *dev[] = {c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->d_cnt2b) hipFree(c->d_cnt2b);
+  for (int i = 0; i < 2; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
+  if (c->scan_stream) hipStreamDestroy(c->scan_stream);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1056,6 +1177,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   c->qt = 16;
   const char *env_qt = getenv("UVAIA_GPU_QT");
   if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
+  const char *env_scan = getenv("UVAIA_GPU_SCAN");
+  if (env_scan) c->scan_variant = (strcmp(env_scan, "sgpr") == 0) ? 0 : 1;
   const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
   c->fullscan = env_full && atoi(env_full) != 0;
   c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
@@ -1102,6 +1225,20 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         if (s6[4] & ~one) { int &cnt = ambq[(size_t)i * AMB_STRIDE]; if (cnt < AMB_CAP) ambq[(size_t)i * AMB_STRIDE + 1 + cnt] = w; cnt++; }
       }
       OPENCHK(hipMalloc(&c->d_qp2, qp2.size() * 4)); OPENCHK(hipMemcpy(c->d_qp2, qp2.data(), qp2.size() * 4, hipMemcpyHostToDevice));
+    }
+    {  // LDS-staging layout: [query tile of 16][w4 (padded to 8)][query in tile][word j] -> uint4 of the four planes
+      c->W4pad = (c->W4 + 7) / 8 * 8;
+      const int ntile = c->nq_pad / 16;
+      std::vector<uint32_t> qvh((size_t)ntile * c->W4pad * 16 * 4 * 4, 0u);
+      for (int i = 0; i < c->nq; i++) for (int w = 0; w < c->W4 * 4; w++) {
+        uint32_t pl[4];
+        if (c->acgt) { const uint32_t *s4 = qp.data() + (size_t)i * row_words + (size_t)w * 4; pl[0] = s4[0]; pl[1] = s4[1]; pl[2] = s4[2]; pl[3] = s4[3]; }
+        else { const uint32_t *s6 = qp.data() + (size_t)i * row_words + (size_t)w * 6; const uint32_t one = s6[5];
+               pl[0] = (s6[1] | s6[3]) & one; pl[1] = (s6[2] | s6[3]) & one; pl[2] = one; pl[3] = s6[4]; }
+        uint32_t *d = qvh.data() + ((((size_t)(i / 16) * c->W4pad + (w >> 2)) * 16 + (i % 16)) * 4 + (w & 3)) * 4;
+        d[0] = pl[0]; d[1] = pl[1]; d[2] = pl[2]; d[3] = pl[3];
+      }
+      OPENCHK(hipMalloc(&c->d_qv, qvh.size() * 4)); OPENCHK(hipMemcpy(c->d_qv, qvh.data(), qvh.size() * 4, hipMemcpyHostToDevice));
     }
     OPENCHK(hipMalloc(&c->d_amb_q, ambq.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_amb_q, ambq.data(), ambq.size() * sizeof(int), hipMemcpyHostToDevice));
   }
@@ -1151,6 +1288,8 @@ int uvaia_gpu_reset(uvaia_gpu_ctx *c)
   HIPCHK(c, hipMemsetAsync(c->d_heap, 0, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), c->stream));
   hipLaunchKernelGGL(init_state_kernel, dim3((c->nq + 255) / 256), dim3(256), 0, c->stream, c->d_T, c->d_n, c->nq, c->nchar);
   HIPCHK(c, hipGetLastError());
+  if (c->d_entered && c->db_n) HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
+  if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1255,6 +1394,18 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
   if (pool < 1 || pool > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "pool must be in [1, max_pool=%zu]", c->max_pool);
   if (!c->db_n) return 0;
   HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
+  if (!c->fullscan) {
+    // two streams: while batch i goes through the gate, batch i+1 is already being scanned (the scan needs no state)
+    const size_t nb = (c->db_n + pool - 1) / pool;
+    int rc = uvaia_gpu_slice_scan(c, 0, std::min(pool, c->db_n), 0);
+    if (rc) return rc;
+    for (size_t i = 0; i < nb; i++) {
+      const size_t a = i * pool;
+      if (i + 1 < nb) { rc = uvaia_gpu_slice_scan(c, a + pool, std::min(pool, c->db_n - a - pool), (int)((i + 1) & 1)); if (rc) return rc; }
+      rc = uvaia_gpu_slice_replay(c, (int)(i & 1), ordinal0 + (long long)a, 1);
+      if (rc) return rc;
+    }
+  } else
   for (size_t a = 0; a < c->db_n; a += pool) {
     const size_t b = std::min(c->db_n, a + pool);
     const long long tf = (long long)(a / 64);
@@ -1274,6 +1425,7 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
 int uvaia_gpu_sync(uvaia_gpu_ctx *c)
 {
   if (!c) return UVAIA_GPU_EINVAL;
+  if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return collect_events(c);
 }
@@ -1322,6 +1474,98 @@ int uvaia_gpu_replay_stats(uvaia_gpu_ctx *c, unsigned long long out[3], int rese
   HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
   if (reset) HIPCHK(c, hipMemset(c->d_stats, 0, sizeof h));
+  return 0;
+}
+
+// ---- ring mode (multi-GPU, DESIGN.md "Multi-GPU"): the database is dealt block-cyclically, every rank scans its slice
+// of a stripe concurrently, and the small per-query state travels rank to rank so that each query still sees the
+// references in stream order.  state blob = snapshot, n[q], T[q], heap[q][k+1][8]  (all int32).
+size_t uvaia_gpu_state_bytes(const uvaia_gpu_ctx *c)
+{
+  return c ? sizeof(int) * (4 + 2 * (size_t)c->nq + (size_t)c->nq * (c->k + 1) * HEAP_ENTRY) : 0;
+}
+
+int uvaia_gpu_state_export(uvaia_gpu_ctx *c, void *dst)
+{ // dst: device (or pinned host) memory of uvaia_gpu_state_bytes(); ordered on the replay stream, then waited for
+  if (!c || !dst) return UVAIA_GPU_EINVAL;
+  int *d = (int *)dst;
+  HIPCHK(c, hipMemcpyAsync(d, c->d_snap, sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + 4, c->d_n, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + 4 + c->nq, c->d_T, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + 4 + 2 * (size_t)c->nq, c->d_heap, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int uvaia_gpu_state_import(uvaia_gpu_ctx *c, const void *src)
+{
+  if (!c || !src) return UVAIA_GPU_EINVAL;
+  const int *d = (const int *)src;
+  HIPCHK(c, hipMemcpyAsync(c->d_snap, d, sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_n, d + 4, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_T, d + 4 + c->nq, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_heap, d + 4 + 2 * (size_t)c->nq, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), hipMemcpyDefault, c->stream));
+  return 0;
+}
+
+// counts of database references [first, first+n) into counter buffer `buf` (0/1), asynchronously on the scan stream
+int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
+{
+  if (!c || buf < 0 || buf > 1) return UVAIA_GPU_EINVAL;
+  if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "ring mode needs the two-counter scan");
+  if (first + n > c->db_n || n > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database or above max_pool", first, n);
+  if (!c->scan_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
+  }
+  if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
+  if (buf == 1 && !c->d_cnt2b) HIPCHK(c, hipMalloc(&c->d_cnt2b, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  const long long tf = (long long)(first / 64);
+  const int n_tiles = n ? (int)((first + n + 63) / 64 - first / 64) : 0;
+  c->slice_tf[buf] = tf; c->slice_tiles[buf] = n_tiles;
+  c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
+  const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
+  int rc = launch_scan2(c, c->d_db, tf, n_tiles, buf ? c->d_cnt2b : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream);
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->scan_done[buf], c->scan_stream));
+  return 0;
+}
+
+// gate + heaps over the slice scanned into `buf`, from the state currently held (imported or local).
+// stripe_start != 0: this slice opens a batch, so the batch snapshot (cq->max_incompatible, src/nearest.c:290-291) is
+// taken from the current state; otherwise the imported snapshot of the stripe is used.
+int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start)
+{
+  if (!c || buf < 0 || buf > 1 || !c->scan_stream) return c ? fail(c, UVAIA_GPU_ESTATE, "slice_replay without slice_scan") : UVAIA_GPU_EINVAL;
+  const int n_tiles = c->slice_tiles[buf], rb = c->slice_rb[buf], re = c->slice_re[buf];
+  const long long tf = c->slice_tf[buf];
+  if (stripe_start) hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap);
+  if (re <= rb) return 0;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->scan_done[buf], 0));
+  const int ppad = n_tiles * 64;
+  if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  const int2 *cnt = buf ? c->d_cnt2b : c->d_cnt2;
+  const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_STRIDE;
+  uint8_t *ent = c->d_entered + tf * 64;
+  if (c->acgt) hipLaunchKernelGGL((replay2_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0,
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
+  else         hipLaunchKernelGGL((replay2_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0,
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->replay_done[buf], c->stream));
+  c->replay_recorded[buf] = true;
+  c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf;
+  return 0;
+}
+
+int uvaia_gpu_entered_flags(uvaia_gpu_ctx *c, uint8_t *out, int clear)
+{ // "entered any heap" flags of the resident database accumulated by slice replays (and by search_resident)
+  if (!c) return UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (out && c->db_n) HIPCHK(c, hipMemcpy(out, c->d_entered, c->db_n, hipMemcpyDeviceToHost));
+  if (clear && c->db_n) HIPCHK(c, hipMemset(c->d_entered, 0, ((c->db_n + 63) / 64) * 64));
   return 0;
 }
 

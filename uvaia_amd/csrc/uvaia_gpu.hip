@@ -86,6 +86,8 @@ struct uvaia_gpu_ctx {
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
   uint32_t *d_cpm = nullptr;     // consensus restricted to idx_m (radius search)
   uint32_t *d_qpoly = nullptr;   // queries restricted to idx (radius search), [nq_pad][W4][4][NQ]
+  uint32_t *d_cmrows = nullptr;  // 32 pseudo-query rows: [0] consensus on idx_c, [1] consensus on idx_m (radius search)
+  int4 *d_cnt_cm = nullptr; size_t cnt_cm_cap = 0; int *d_mindist = nullptr;
   std::vector<uint32_t> h_qp_poly_src;  // kept to build d_qpoly lazily
   // heaps / state
   int *d_heap = nullptr, *d_n = nullptr, *d_T = nullptr, *d_snap = nullptr, *d_err = nullptr;
@@ -935,6 +937,29 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned long long)n_admit); atomicAdd(&stats[1], (unsigned long long)n_demand); atomicAdd(&stats[2], (unsigned long long)n_dense); }
 }
 
+// Radius search, per reference: replays seq_ball_against_query_structure() (src/fastaseq.c:660-696) on exact distances.
+// dist_cm[0][r], dist_cm[1][r]: distance to the consensus on idx_c / idx_m; dist_q[q][r]: distance to query q on idx.
+// A truncated scan of the reference returns min(true distance, maxdist), which is all that is needed here.
+template <bool ACGT>
+__global__ void ball_reduce_kernel(const int4 *__restrict__ cnt_cm, int ppad_cm, const int4 *__restrict__ cnt_q, int ppad, int nq, int n_ref, int radius,
+                                   int *__restrict__ mindist)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_ref) return;
+  auto dist = [](const int4 c) { return ACGT ? c.x : (c.w - c.y); };   // both ACGT & differ | both valid & characters differ
+  int md = min(dist(cnt_cm[r]), radius);                                  // idx_c pass, maxdist = radius
+  if (md < radius) {
+    md += min(dist(cnt_cm[(size_t)ppad_cm + r]), radius);                 // idx_m pass against the consensus
+    if (md < radius) {
+      const int c = md;                                                   // c_dist; *min_dist == c on loop entry
+      int cur = c;
+      for (int q = 0; q < nq && cur + c >= radius; q++) cur = min(dist(cnt_q[(size_t)q * ppad + r]), radius - c);
+      md = cur + c;
+    }
+  }
+  mindist[r] = md;
+}
+
 __global__ void snapshot_kernel(const int *__restrict__ T, int nq, int *__restrict__ snap)
 { // cq->max_incompatible = max over heaps (src/nearest.c:290-291)
   __shared__ int red[256];
@@ -1144,7 +1169,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+  void *dev[] = {c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -1245,6 +1270,9 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_qpoly, qpoly.size() * 4)); OPENCHK(hipMemcpy(c->d_qpoly, qpoly.data(), qpoly.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cp, cp.size() * 4)); OPENCHK(hipMemcpy(c->d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cpm, cpm.size() * 4)); OPENCHK(hipMemcpy(c->d_cpm, cpm.data(), cpm.size() * 4, hipMemcpyHostToDevice));
+  OPENCHK(hipMalloc(&c->d_cmrows, 32 * row_words * 4)); OPENCHK(hipMemset(c->d_cmrows, 0, 32 * row_words * 4));
+  OPENCHK(hipMemcpy(c->d_cmrows, cp.data(), row_words * 4, hipMemcpyHostToDevice));
+  OPENCHK(hipMemcpy(c->d_cmrows + row_words, cpm.data(), row_words * 4, hipMemcpyHostToDevice));
 
   // ---- state
   OPENCHK(hipMalloc(&c->d_heap, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int)));
@@ -1267,6 +1295,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_rt, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_tr, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_entered, c->pool_pad)); c->entered_cap = c->pool_pad;
+  OPENCHK(hipMemset(c->d_entered, 0, c->pool_pad));
   OPENCHK(hipMalloc(&c->d_stage, (size_t)PACK_CHUNK * c->pitch));
   OPENCHK(hipHostMalloc(&c->h_stage, (size_t)PACK_CHUNK * c->pitch, hipHostMallocDefault));
   memset(c->h_stage, 'N', (size_t)PACK_CHUNK * c->pitch);
@@ -1359,6 +1388,7 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
     hipFree(c->d_entered); c->d_entered = nullptr;
     HIPCHK(c, hipMalloc(&c->d_entered, tiles * 64)); c->entered_cap = tiles * 64;
   }
+  HIPCHK(c, hipMemset(c->d_entered, 0, c->entered_cap));
   return 0;
 }
 
@@ -1571,8 +1601,30 @@ int uvaia_gpu_entered_flags(uvaia_gpu_ctx *c, uint8_t *out, int clear)
 
 int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radius, int *mindist)
 {
-  (void)seq; (void)n_ref; (void)radius; (void)mindist;
-  return fail(c, UVAIA_GPU_ESTATE, "radius search is not built yet");
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (n_ref < 0 || (n_ref > 0 && (!seq || !mindist))) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
+  if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
+  if (n_ref == 0) return 0;
+  int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, 0);
+  if (rc) return rc;
+  const int n_tiles = (n_ref + 63) / 64, ppad = n_tiles * 64;
+  rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
+  if (c->cnt_cm_cap < (size_t)32 * c->pool_pad) {
+    if (c->d_cnt_cm) HIPCHK(c, hipFree(c->d_cnt_cm));
+    HIPCHK(c, hipMalloc(&c->d_cnt_cm, (size_t)32 * c->pool_pad * sizeof(int4))); c->cnt_cm_cap = (size_t)32 * c->pool_pad;
+    if (!c->d_mindist) HIPCHK(c, hipMalloc(&c->d_mindist, c->pool_pad * sizeof(int)));
+  }
+  const bool prof = c->profile; c->profile = false;     // these launches are not the nearest-neighbour scan the statistics describe
+  rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_cmrows, 32, c->d_cnt_cm, ppad, 0.0);
+  if (!rc) rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_qpoly, c->nq_pad, c->d_cnt, ppad, 0.0);
+  c->profile = prof;
+  if (rc) return rc;
+  if (c->acgt) hipLaunchKernelGGL((ball_reduce_kernel<true>), dim3((n_ref + 255) / 256), dim3(256), 0, c->stream, c->d_cnt_cm, ppad, c->d_cnt, ppad, c->nq, n_ref, radius, c->d_mindist);
+  else         hipLaunchKernelGGL((ball_reduce_kernel<false>), dim3((n_ref + 255) / 256), dim3(256), 0, c->stream, c->d_cnt_cm, ppad, c->d_cnt, ppad, c->nq, n_ref, radius, c->d_mindist);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(mindist, c->d_mindist, (size_t)n_ref * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 }  // extern "C"

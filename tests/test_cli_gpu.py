@@ -1,0 +1,116 @@
+"""End-to-end tests of the drop-in command lines (bin/uvaia, bin/uvaiaball) and of the radius search, on a GPU box.
+Outputs (CSV rows, dumped sequences and their order) must equal what the oracle's restatement of the reference's main loops
+gives for the same files and options."""
+import csv
+import io
+import lzma
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fixtures as F
+import oracle_lib as O
+from uvaia_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UVAIA = os.path.join(ROOT, "bin", "uvaia")
+UVAIABALL = os.path.join(ROOT, "bin", "uvaiaball")
+
+
+def _write_fasta(path, names, seqs, opener=open, width=None):
+    with opener(path, "wb") as fh:
+        for n, s in zip(names, seqs):
+            fh.write(b">" + n.encode() + b"\n")
+            if width:
+                for a in range(0, len(s), width):
+                    fh.write(s[a:a + width] + b"\n")
+            else:
+                fh.write(s + b"\n")
+
+
+def _read_xz_text(path):
+    with lzma.open(path, "rt") as fh:
+        return fh.read()
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory, bundled_db):
+    d = tmp_path_factory.mktemp("cli")
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:10]
+    _write_fasta(d / "query.fa", qn, [by[n] for n in qn], width=70)          # multi-line FASTA
+    _write_fasta(d / "ref1.aln.xz", names[:1200], seqs[:1200], opener=lzma.open)
+    _write_fasta(d / "ref2.fa", names[1200:1500], seqs[1200:1500])
+    return d, qn, [by[n] for n in qn], names[:1500], seqs[:1500]
+
+
+@pytest.mark.parametrize("extra,kw", [
+    ([], {}),
+    (["--acgt"], {"acgt": True}),
+    (["--trim", "230", "-x"], {"trim": 230, "exclude_self": True}),
+    (["-k", "-n", "1"], {"keep_resolved": True, "nbest": 1}),
+])
+def test_uvaia_cli_matches_oracle(files, extra, kw):
+    d, qn, qs, rnames, rseqs = files
+    nbest = kw.get("nbest", 5)
+    out = str(d / ("out_" + "_".join(x.strip("-") for x in extra) if extra else "out_default"))
+    cmd = [UVAIA, "-r", str(d / "ref1.aln.xz"), "-r", str(d / "ref2.fa"), str(d / "query.fa"), "-p", "64", "-o", out]
+    if "nbest" not in kw:
+        cmd += ["-n", str(nbest)]
+    subprocess.run(cmd + extra, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    q = O.Query(qs, qn, trim=kw.get("trim", 0), acgt=kw.get("acgt", False), keep_resolved=kw.get("keep_resolved", False))
+    gold = O.search(q, rseqs, rnames, pool=64, nbest=nbest, exclude_self=kw.get("exclude_self", False), file_breaks=(1200,))
+    # table
+    rows = list(csv.reader(io.StringIO(_read_xz_text(out + ".csv.xz"))))
+    hdr = rows[0]
+    assert hdr[:4] == ["query", "reference", "rank", "ACGT_matches"]
+    assert hdr[4] == ("valid_ACGT_comparisons" if kw.get("acgt") else "text_matches")
+    want = []
+    for iq in range(q.ntax):
+        for rank, (o, name, s) in enumerate(gold.rows[iq], 1):
+            want.append([q.names[iq], name, str(rank)] + [str(v) for v in s])
+    assert rows[1:] == want
+    # dump: every reference that ever entered a heap, in stream order
+    dump_names, dump_seqs = F.read_fasta_bytes(lzma.open(out + ".aln.xz", "rb").read())
+    assert dump_names == [rnames[i] for i in gold.saved]
+    assert dump_seqs == [rseqs[i] for i in gold.saved]
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("dist", [0, 1, 5])
+def test_ball_api_matches_oracle(bundled_db, acgt, dist):
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:12]
+    q = O.Query([by[n] for n in qn], qn, dist=dist, acgt=acgt, is_ball=True)
+    refs = seqs[:900]
+    md_want, _ = q.ball(refs, ambig_r=0.001)                 # ambig_r ~ 0: no reference is filtered before scoring
+    with capi.Engine.from_query(q, nbest=2, max_pool=512) as eng:
+        got = np.concatenate([eng.ball(refs[a:a + 512], q.dist + 1) for a in range(0, len(refs), 512)])
+    assert np.array_equal(got, md_want)
+
+
+def test_ball_synthetic_many_radii():
+    refs, root, cols = F.synth_alignment(400, 2000, seed=61, p_snp=0.003)
+    qs, _, _ = F.synth_alignment(15, 2000, seed=62, root=root, poly_cols=cols, p_snp=0.003)
+    for acgt in (False, True):
+        for dist in (0, 2, 7, 30):
+            q = O.Query(qs, ["q%d" % i for i in range(len(qs))], dist=dist, acgt=acgt, is_ball=True)
+            md_want, _ = q.ball(refs, ambig_r=0.001)
+            with capi.Engine.from_query(q, nbest=2, max_pool=512) as eng:
+                assert np.array_equal(eng.ball(refs, q.dist + 1), md_want), (acgt, dist)
+
+
+def test_uvaiaball_cli_matches_oracle(files):
+    d, qn, qs, rnames, rseqs = files
+    out = str(d / "ball_out")
+    subprocess.run([UVAIABALL, "-r", str(d / "ref1.aln.xz"), str(d / "query.fa"), "-d", "3", "-p", "100", "-o", out],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    q = O.Query(qs, qn, dist=3, is_ball=True)
+    md, keep = q.ball(rseqs[:1200], ambig_r=0.5)
+    dump_names, dump_seqs = F.read_fasta_bytes(lzma.open(out + ".aln.xz", "rb").read())
+    assert dump_names == [rnames[i] for i in np.nonzero(keep)[0]]

@@ -76,7 +76,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qp2 = nullptr;     // [nq_pad][W4][4][4]    (lo, hi, isACGT, valid) for the two-counter scan (default mode)
   uint4 *d_qv = nullptr;         // [nq_pad/16][W4pad][16][4]  the same planes laid out for LDS staging (scan2v_kernel)
   int W4pad = 0;
-  int scan_variant = 1;          // 0 = scalar-operand scan2_*_kernel, 1 = LDS-broadcast scan2v_kernel (UVAIA_GPU_SCAN=sgpr|lds)
+  int scan_variant = 0;          // 0 = scalar-operand scan2_*_kernel (default), 1 = LDS-broadcast scan2v_kernel (UVAIA_GPU_SCAN=lds)
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int2 *d_cnt2 = nullptr;        // [nq_pad][pool_pad] two-counter scan output
@@ -335,6 +335,19 @@ __global__ __launch_bounds__(256) void scan_acgt_kernel(const uint4 *__restrict_
   for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int4(acc[q][0], acc[q][1], acc[q][2], 0);
 }
 
+// XCD-aware work mapping for the scans (1-D grid).  Blocks are dealt round-robin over the 8 XCDs (each with its own L2), so
+// block b runs on XCD b % 8.  All query tiles of one reference group are given ids with the same b % 8: the group's tiles
+// are then fetched by ONE L2 instead of eight, and consecutive slots of an XCD share the group (temporal locality).
+// Placement only affects speed/traffic, never results.
+static __device__ __forceinline__ bool scan_work_item(int n_qtiles, int n_groups, int &qtile, int &group)
+{
+  const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+  qtile = slot % n_qtiles;
+  group = (slot / n_qtiles) * 8 + xcd;
+  return group < n_groups;
+}
+static inline unsigned scan_grid_size(int n_qtiles, int n_groups) { return (unsigned)n_qtiles * (unsigned)((n_groups + 7) / 8) * 8u; }
+
 // ------------------------------------------------------------------------------------------------------------
 // device: the two-counter pair scan (production path)
 // ------------------------------------------------------------------------------------------------------------
@@ -346,12 +359,14 @@ __global__ __launch_bounds__(256) void scan_acgt_kernel(const uint4 *__restrict_
 // 4 logic ops + 2 v_bcnt per pair-word.
 template <int QT>
 __global__ __launch_bounds__(256) void scan2_iupac_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
-                                                           const uint32_t *__restrict__ qp2, int2 *__restrict__ out, int ppad)
+                                                           const uint32_t *__restrict__ qp2, int2 *__restrict__ out, int ppad, int n_qtiles)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int trel = blockIdx.y * 4 + wave;
+  int qtile, group;
+  if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
+  const int trel = group * 4 + wave;
   if (trel >= n_tiles) return;
-  const int q0 = blockIdx.x * QT;
+  const int q0 = qtile * QT;
   int acc[QT][2];
 #pragma unroll
   for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = 0; }
@@ -398,12 +413,14 @@ __global__ __launch_bounds__(256) void scan2_iupac_kernel(const uint4 *__restric
 
 template <int QT>
 __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
-                                                          const uint32_t *__restrict__ qp, int2 *__restrict__ out, int ppad)
+                                                          const uint32_t *__restrict__ qp, int2 *__restrict__ out, int ppad, int n_qtiles)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int trel = blockIdx.y * 4 + wave;
+  int qtile, group;
+  if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
+  const int trel = group * 4 + wave;
   if (trel >= n_tiles) return;
-  const int q0 = blockIdx.x * QT;
+  const int q0 = qtile * QT;
   int acc[QT][2];
 #pragma unroll
   for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = 0; }
@@ -443,19 +460,21 @@ __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict
 // R tiles (R references per lane) so that one LDS read feeds R pair-words.
 template <int QT, int R, bool ACGT>
 __global__ __launch_bounds__(256) void scan2v_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4, int W4pad,
-                                                      const uint4 *__restrict__ qv, int2 *__restrict__ out, int ppad)
+                                                      const uint4 *__restrict__ qv, int2 *__restrict__ out, int ppad, int n_qtiles)
 {
   constexpr int CHW = 8, P = ACGT ? 3 : 4, CHUNK = CHW * QT * 4, PER_THREAD = CHUNK / 256;
   static_assert(CHUNK % 256 == 0, "staging assumes a multiple of the block size");
   __shared__ uint4 lq[2][CHUNK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t0 = (blockIdx.y * 4 + wave) * R;
+  int qtile, group;
+  if (!scan_work_item(n_qtiles, (n_tiles + 4 * R - 1) / (4 * R), qtile, group)) return;     // whole block leaves together
+  const int t0 = (group * 4 + wave) * R;
   int acc[QT][R][2];
 #pragma unroll
   for (int q = 0; q < QT; q++)
 #pragma unroll
     for (int r = 0; r < R; r++) { acc[q][r][0] = acc[q][r][1] = 0; }
-  const uint4 *qsrc = qv + (size_t)blockIdx.x * W4pad * QT * 4;
+  const uint4 *qsrc = qv + (size_t)qtile * W4pad * QT * 4;
   const int nchunks = W4pad / CHW;
   uint4 st[PER_THREAD];
 #pragma unroll
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256) void scan2v_kernel(const uint4 *__restrict__ d
     }
     __syncthreads();
   }
-  const int q0 = blockIdx.x * QT;
+  const int q0 = qtile * QT;
 #pragma unroll
   for (int r = 0; r < R; r++) {
     if (t0 + r >= n_tiles) continue;
@@ -1022,10 +1041,10 @@ int pack_query_row(const uint8_t *code_tab, const char *row, int nchar, int lo, 
   return 0;
 }
 
-int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, const uint32_t *qp, int nq_pad, int4 *out, int ppad, double bytes)
+int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, const uint32_t *qp, int n_rows, int4 *out, int ppad, double bytes)
 {
   if (n_tiles <= 0) return 0;
-  dim3 grid((unsigned)(nq_pad / c->qt), (unsigned)((n_tiles + 3) / 4)), block(256);
+  dim3 grid((unsigned)((n_rows + c->qt - 1) / c->qt), (unsigned)((n_tiles + 3) / 4)), block(256);   // only tiles holding real queries
   ScanEvt ev{};
   if (c->profile) {
     HIPCHK(c, hipEventCreate(&ev.a)); HIPCHK(c, hipEventCreate(&ev.b));
@@ -1044,7 +1063,8 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int
 {
   if (n_tiles <= 0) return 0;
   if (!stream) stream = c->stream;
-  dim3 grid((unsigned)(c->nq_pad / c->qt), (unsigned)((n_tiles + 3) / 4)), block(256);
+  const int n_qtiles = (c->nq + c->qt - 1) / c->qt;
+  dim3 grid(scan_grid_size(n_qtiles, (n_tiles + 3) / 4)), block(256);
   ScanEvt ev{};
   if (c->profile) {
     HIPCHK(c, hipEventCreate(&ev.a)); HIPCHK(c, hipEventCreate(&ev.b));
@@ -1053,14 +1073,15 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int
   const uint32_t *qp = c->acgt ? c->d_qp : c->d_qp2;
   if (c->scan_variant == 1) {
     constexpr int QTV = 16, RV = 2;
-    dim3 gridv((unsigned)(c->nq_pad / QTV), (unsigned)((n_tiles + 4 * RV - 1) / (4 * RV)));
-    if (c->acgt) hipLaunchKernelGGL((scan2v_kernel<QTV, RV, true>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad);
-    else         hipLaunchKernelGGL((scan2v_kernel<QTV, RV, false>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad);
+    const int nqtv = (c->nq + QTV - 1) / QTV;
+    dim3 gridv(scan_grid_size(nqtv, (n_tiles + 4 * RV - 1) / (4 * RV)));
+    if (c->acgt) hipLaunchKernelGGL((scan2v_kernel<QTV, RV, true>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
+    else         hipLaunchKernelGGL((scan2v_kernel<QTV, RV, false>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, stream)); ev.bytes = bytes; c->evts.push_back(ev); }
     return 0;
   }
-#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad)
+#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles)
   if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan2_acgt_kernel, 8); break; case 32: LAUNCH(scan2_acgt_kernel, 32); break; default: LAUNCH(scan2_acgt_kernel, 16); } }
   else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
 #undef LAUNCH
@@ -1107,7 +1128,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   if (c->fullscan) {
     int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
-    rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq_pad, c->d_cnt, ppad, bytes);
+    rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq, c->d_cnt, ppad, bytes);
     if (rc) return rc;
     if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
     else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
@@ -1199,11 +1220,11 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   c->P = c->acgt ? 3 : 4; c->NQ = c->acgt ? 4 : 6;
   c->W = (c->nchar + 31) / 32; c->W4 = (c->W + 3) / 4;
   c->k = heap_size < 2 ? 2 : heap_size;                      // src/min_heap.c:58
-  c->qt = 16;
+  c->qt = c->nq <= 8 ? 8 : 16;
   const char *env_qt = getenv("UVAIA_GPU_QT");
   if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
   const char *env_scan = getenv("UVAIA_GPU_SCAN");
-  if (env_scan) c->scan_variant = (strcmp(env_scan, "sgpr") == 0) ? 0 : 1;
+  if (env_scan) c->scan_variant = (strcmp(env_scan, "lds") == 0) ? 1 : 0;
   const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
   c->fullscan = env_full && atoi(env_full) != 0;
   c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
@@ -1469,7 +1490,7 @@ int uvaia_gpu_last_batch_scores(uvaia_gpu_ctx *c, int *out, int n_ref)
   if (!c->fullscan) {   // the production path keeps two counters per pair: recount the batch with the four-counter kernel
     int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->last_ppad); if (rc) return rc;
     const bool prof = c->profile; c->profile = false;
-    rc = launch_scan(c, c->last_tiles, c->last_tile_first, c->last_ntiles, c->d_qp, c->nq_pad, c->d_cnt, c->last_ppad, 0.0);
+    rc = launch_scan(c, c->last_tiles, c->last_tile_first, c->last_ntiles, c->d_qp, c->nq, c->d_cnt, c->last_ppad, 0.0);
     c->profile = prof;
     if (rc) return rc;
   }
@@ -1615,8 +1636,8 @@ int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radi
     if (!c->d_mindist) HIPCHK(c, hipMalloc(&c->d_mindist, c->pool_pad * sizeof(int)));
   }
   const bool prof = c->profile; c->profile = false;     // these launches are not the nearest-neighbour scan the statistics describe
-  rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_cmrows, 32, c->d_cnt_cm, ppad, 0.0);
-  if (!rc) rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_qpoly, c->nq_pad, c->d_cnt, ppad, 0.0);
+  rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_cmrows, 2, c->d_cnt_cm, ppad, 0.0);
+  if (!rc) rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
   c->profile = prof;
   if (rc) return rc;
   if (c->acgt) hipLaunchKernelGGL((ball_reduce_kernel<true>), dim3((n_ref + 255) / 256), dim3(256), 0, c->stream, c->d_cnt_cm, ppad, c->d_cnt, ppad, c->nq, n_ref, radius, c->d_mindist);

@@ -280,3 +280,31 @@ def test_ring_mode_with_several_contexts_on_one_gpu(synth, acgt, world, slice_si
     finally:
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("nbest,n_refs", [(2500, 700), (600, 700)])
+def test_large_heaps(synth, nbest, n_refs):
+    """k = 2500 needs more than 64 KB of LDS per query heap (dynamic LDS attribute); k = 600 < n_refs fills and churns a big heap."""
+    refs, qs = synth
+    q = O.Query(qs[:6], _names(6, "q"))
+    _assert_same_search(q, refs[:n_refs], 256, nbest)
+
+
+def test_host_non_n_does_not_leak_into_counts(synth):
+    """cq->non_n only feeds the last score column (src/nearest.c:501); handing the engine a different number must change
+    that column and nothing else (the valid-pair counter uses the engine's own per-reference total)."""
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"))
+    refs = refs[:200]
+
+    def kept(non_n):
+        with capi.Engine.from_query(q, nbest=300, max_pool=256) as eng:      # heap larger than the stream: everything is kept
+            eng.push(refs, non_n=non_n)
+            n, T, sc, od = eng.drain()
+        return [{int(od[iq, s]): tuple(sc[iq, s]) for s in range(1, n[iq] + 1)} for iq in range(q.ntax)]
+
+    base, alt = kept(None), kept(np.full(len(refs), 7, dtype=np.int32))
+    for iq in range(q.ntax):
+        assert base[iq].keys() == alt[iq].keys() and len(base[iq]) == len(refs)
+        for o in base[iq]:
+            assert base[iq][o][:5] == alt[iq][o][:5] and alt[iq][o][5] == 7

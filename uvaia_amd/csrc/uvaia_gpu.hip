@@ -68,7 +68,7 @@ struct uvaia_gpu_ctx {
   int2 *d_cnt2b = nullptr;                // second counter buffer (ring mode, allocated on first use)
   int slice_tiles[2] = {0, 0}, slice_rb[2] = {0, 0}, slice_re[2] = {0, 0};
   long long slice_tf[2] = {0, 0};
-  int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16;
+  int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16, n_idx_c = 0;
   size_t trim = 0;
   size_t max_pool = 0, pool_pad = 0;
   // query side
@@ -79,6 +79,7 @@ struct uvaia_gpu_ctx {
   int scan_variant = 0;          // 0 = scalar-operand scan2_*_kernel (default), 1 = LDS-broadcast scan2v_kernel (UVAIA_GPU_SCAN=lds)
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
+  int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
   int2 *d_cnt2 = nullptr;        // [nq_pad][pool_pad] two-counter scan output
   unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
   bool fullscan = false;         // UVAIA_GPU_FULLSCAN=1: four-counter scan + replay over it (kept for A/B and tests)
@@ -155,10 +156,11 @@ template <int P>
 __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restrict__ chars, size_t pitch, int nchar,
                                                          long long slot0, int n_ref, int W4, uint4 *__restrict__ tiles,
                                                          long long tile_base, int *__restrict__ non_n_out, int *__restrict__ amb_out,
-                                                         int *__restrict__ errflag)
+                                                         int *__restrict__ tot_out, int *__restrict__ errflag)
 {
   __shared__ uint8_t lut[256];
   __shared__ int partial[4][64];
+  __shared__ int partial_acgt[4][64];
   __shared__ int amb_n[64];
   __shared__ int amb_w[64][AMB_CAP];
   lut[threadIdx.x] = c_code[threadIdx.x];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
   const bool active = (i >= 0 && i < n_ref);
   const uint8_t *row = chars + (active ? (size_t)i * pitch : 0);
   const bool vec = ((pitch & 15) == 0) && ((((uintptr_t)chars) & 15) == 0);
-  int valid = 0, bad = 0;
+  int valid = 0, n_acgt = 0, bad = 0;
   for (int w4 = wv; w4 < W4; w4 += 4) {
     uint32_t pl[4][4];                               // [plane][j]
 #pragma unroll
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
           uint32_t code = (site0 + s < nchar) ? lut[b[s]] : 0u;
           if (code == 0xFFu) { bad = 1; code = 0; }
           valid += (code != 0);
+          n_acgt += (code != 0) & ((code & (code - 1)) == 0);
           partial_code |= code & (code - 1);
           if (P == 4) {
             a0 |= (code & 1u) << s; a1 |= ((code >> 1) & 1u) << s; a2 |= ((code >> 2) & 1u) << s; a3 |= ((code >> 3) & 1u) << s;
@@ -212,9 +215,12 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
       for (int p = 0; p < P; p++) dst[(size_t)p * 64] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
     }
   }
-  partial[wv][lane] = valid;
+  partial[wv][lane] = valid; partial_acgt[wv][lane] = n_acgt;
   __syncthreads();
   if (wv == 0 && active && non_n_out) non_n_out[slot] = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+  // total the two-counter scan subtracts from: valid sites (default) or ACGT sites (--acgt) of the whole sequence
+  if (wv == 0 && active && tot_out) tot_out[slot] = (P == 4) ? (partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane])
+                                                           : (partial_acgt[0][lane] + partial_acgt[1][lane] + partial_acgt[2][lane] + partial_acgt[3][lane]);
   if (wv == 0 && active && amb_out) {
     int *a = amb_out + (size_t)slot * AMB_STRIDE;
     a[0] = amb_n[lane];
@@ -359,7 +365,7 @@ static inline unsigned scan_grid_size(int n_qtiles, int n_groups) { return (unsi
 // 4 logic ops + 2 v_bcnt per pair-word.
 template <int QT>
 __global__ __launch_bounds__(256) void scan2_iupac_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
-                                                           const uint32_t *__restrict__ qp2, int2 *__restrict__ out, int ppad, int n_qtiles)
+                                                           const uint32_t *__restrict__ qp2, int2 *__restrict__ out, int ppad, int n_qtiles, const int *__restrict__ tot)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int qtile, group;
@@ -396,24 +402,30 @@ __global__ __launch_bounds__(256) void scan2_iupac_kernel(const uint4 *__restric
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const uint32_t qL = cur.v[j * 4 + 0], qH = cur.v[j * 4 + 1], qI = cur.v[j * 4 + 2], qV = cur.v[j * 4 + 3];
+        const uint32_t qL = cur.v[j * 4 + 0], qH = cur.v[j * 4 + 1], qI = cur.v[j * 4 + 2];
         const uint32_t d = rL[j] ^ qL;
         const uint32_t y = B3(rH[j], qH, d, (TT_A ^ TT_B) | TT_C);
         acc[q][0] = bcnt_acc(B3(y, rI[j], qI, ~TT_A & TT_B & TT_C), acc[q][0]);
-        acc[q][1] = bcnt_acc(rV[j] & qV, acc[q][1]);
+      }
+      // valid pairs = valid(reference) - #(reference valid & query invalid): only word groups where this query has an invalid
+      // site can contribute (N runs, gaps, the trimmed ends) -- a wave-uniform test on scalar registers
+      if (~(cur.v[3] & cur.v[7] & cur.v[11] & cur.v[15]) != 0u) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[q][1] = bcnt_acc(rV[j] & ~cur.v[j * 4 + 3], acc[q][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (q + 1 < QT) cur = nxt;
     }
   }
   const size_t r = (size_t)trel * 64 + lane;
+  const int total = tot[r];
 #pragma unroll
-  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], acc[q][1]);
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], total - acc[q][1]);
 }
 
 template <int QT>
 __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict__ db, long long tile_first, int n_tiles, int W4,
-                                                          const uint32_t *__restrict__ qp, int2 *__restrict__ out, int ppad, int n_qtiles)
+                                                          const uint32_t *__restrict__ qp, int2 *__restrict__ out, int ppad, int n_qtiles, const int *__restrict__ tot)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int qtile, group;
@@ -443,15 +455,20 @@ __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict
         const uint32_t d = rL[j] ^ qL;
         const uint32_t y = B3(rH[j], qH, d, (TT_A ^ TT_B) | TT_C);
         acc[q][0] = bcnt_acc(B3(y, rI[j], qI, TT_A & TT_B & TT_C), acc[q][0]);
-        acc[q][1] = bcnt_acc(rI[j] & qI, acc[q][1]);
+      }
+      // comparable sites = ACGT(reference) - #(reference ACGT & query not ACGT): only groups where the query is not all ACGT
+      if (~(cur.v[2] & cur.v[6] & cur.v[10] & cur.v[14]) != 0u) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[q][1] = bcnt_acc(rI[j] & ~cur.v[j * 4 + 2], acc[q][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (q + 1 < QT) cur = nxt;
     }
   }
   const size_t r = (size_t)trel * 64 + lane;
+  const int total = tot[r];
 #pragma unroll
-  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], acc[q][1]);
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], total - acc[q][1]);
 }
 
 // LDS-broadcast variant of the two-counter scan.  Measured on MI355X (profiles/r01_valu_rate_microbench.txt): a VALU
@@ -566,6 +583,7 @@ __global__ __launch_bounds__(256) void consensus_kernel(const uint4 *__restrict_
                                                          int4 *__restrict__ rt, int4 *__restrict__ tr)
 {
   constexpr int P = ACGT ? 3 : 4, NQ = ACGT ? 4 : 6;
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int trel = blockIdx.x * 4 + wave;
   if (trel >= n_tiles) return;
@@ -769,6 +787,51 @@ __global__ __launch_bounds__(64) void replay_kernel(const int4 *__restrict__ cnt
   }
 }
 
+// ---- wave-cooperative heap operations (same comparisons and swaps as heap_sift_down/up above, hence the same layout):
+// lanes 0..7 each hold one of the 8 ints of an entry, the lexicographic compare is a ballot + first-set-bit, a swap is one
+// parallel read and write.  Every lane of the wave must call these (uniform control flow); h lives in LDS.
+static __device__ __forceinline__ bool wave_entry_better(const int *h, int a, int b, int lane)
+{ // entry a ranks strictly ahead of entry b
+  const int i = lane & 7;
+  const int va = h[a * HEAP_ENTRY + i], vb = h[b * HEAP_ENTRY + i];
+  const unsigned long long m = __ballot((i < 6) && (va != vb)) & 0xFFull;
+  if (!m) return false;
+  const int first = __ffsll((long long)m) - 1;
+  return __shfl(va, first) > __shfl(vb, first);
+}
+
+static __device__ __forceinline__ void wave_entry_swap(int *h, int a, int b, int lane)
+{
+  if (lane < HEAP_ENTRY) {
+    const int va = h[a * HEAP_ENTRY + lane], vb = h[b * HEAP_ENTRY + lane];
+    h[a * HEAP_ENTRY + lane] = vb; h[b * HEAP_ENTRY + lane] = va;
+  }
+  __syncthreads();     // one wave per block: an LDS fence + wave barrier
+}
+
+static __device__ void wave_sift_down(int *h, int n, int p, int lane)
+{ // src/min_heap.c:119-133
+  for (;;) {
+    const int c = 2 * p;
+    int pick = p;
+    if (c <= n && wave_entry_better(h, pick, c, lane)) pick = c;
+    if (c + 1 <= n && wave_entry_better(h, pick, c + 1, lane)) pick = c + 1;
+    if (pick == p) return;
+    wave_entry_swap(h, p, pick, lane);
+    p = pick;
+  }
+}
+
+static __device__ void wave_sift_up(int *h, int i, int lane)
+{ // src/min_heap.c:135-147
+  while (i > 1) {
+    const int parent = i / 2;
+    if (!wave_entry_better(h, parent, i, lane)) return;
+    wave_entry_swap(h, parent, i, lane);
+    i = parent;
+  }
+}
+
 // ---- on-demand counters for the pairs that reach the heap -------------------------------------------------------
 static __device__ __forceinline__ int wave_sum(int v)
 {
@@ -837,7 +900,9 @@ static __device__ int wave_acgt_poly_mismatches(const uint4 *__restrict__ db, si
 // round.  Between two admissions the heap state is constant, so the exact tests of src/nearest.c:488-496 and
 // src/min_heap.c:95 are evaluated for 64 references at once (ballot); the first survivor in order gets its missing
 // counters on demand, is compared exactly, and if admitted the remaining lanes are re-tested against the new state.
-template <bool ACGT>
+// CONS = false: no column is constant and complete (query->n_idx_c == 0), every consensus counter is zero and is not loaded;
+// in default mode valid_ref_sites (key 5) is then fetched only for the pairs that reach the exact compare.
+template <bool ACGT, bool CONS>
 __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cnt, int ppad, const int4 *__restrict__ rt, const int4 *__restrict__ tr,
                                                       const int *__restrict__ nonn, const int *__restrict__ amb, int r_begin, int r_end, long long ord_base,
                                                       int *__restrict__ heap_g, int *__restrict__ n_g, int *__restrict__ T_g,
@@ -848,6 +913,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
 {
   extern __shared__ int h[];
   constexpr int U = 4;
+  __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
   const int q = blockIdx.x, lane = threadIdx.x;
   int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
   int n = n_g[q], T = T_g[q];
@@ -865,15 +931,27 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   const int *aq = amb_q + (size_t)q * AMB_STRIDE;
   bool dirty = false;
   unsigned n_admit = 0, n_demand = 0, n_dense = 0;
-  for (int base = r_begin; base < r_end; base += 64 * U) {
-    int2 c[U]; int4 a[U], rc[U]; int nn[U], m[U], K0[U], K1[U], K2[U], K3[U]; bool valid[U];
+  // software pipeline: the counters of round i+1 are requested before round i is processed (the kernel is latency bound:
+  // one wave per query, a few hundred dependent rounds)
+  int2 pc[U]; int4 pa[U], prc[U]; int pnn[U];
+  auto fetch = [&](int base) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int r = base + u * 64 + lane;
-      valid[u] = r < r_end;
-      c[u] = make_int2(0, 0); a[u] = rc[u] = make_int4(0, 0, 0, 0); nn[u] = 0;
-      if (valid[u]) { c[u] = crow[r]; a[u] = rt[r]; rc[u] = tr[r]; nn[u] = nonn[r]; }
+      pc[u] = make_int2(0, 0); pa[u] = prc[u] = make_int4(0, 0, 0, 0); pnn[u] = 0;
+      if (r < r_end) {
+        pc[u] = crow[r];
+        if (CONS) { pa[u] = rt[r]; prc[u] = tr[r]; }
+        if (CONS || ACGT) pnn[u] = nonn[r];
+      }
     }
+  };
+  fetch(r_begin);
+  for (int base = r_begin; base < r_end; base += 64 * U) {
+    int2 c[U]; int4 a[U], rc[U]; int nn[U], m[U], K0[U], K1[U], K2[U], K3[U]; bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { c[u] = pc[u]; a[u] = pa[u]; rc[u] = prc[u]; nn[u] = pnn[u]; valid[u] = (base + u * 64 + lane) < r_end; }
+    if (base + 64 * U < r_end) fetch(base + 64 * U);
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int mc_true = ACGT ? a[u].x : (a[u].w - a[u].x);
@@ -911,7 +989,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
         const int cx = __shfl(c[u].x, i), cy = __shfl(c[u].y, i);
         const int4 ai = make_int4(__shfl(a[u].x, i), __shfl(a[u].y, i), __shfl(a[u].z, i), __shfl(a[u].w, i));
         const int4 ri = make_int4(__shfl(rc[u].x, i), __shfl(rc[u].y, i), __shfl(rc[u].z, i), __shfl(rc[u].w, i));
-        const int nni = __shfl(nn[u], i);
+        const int nni = (CONS || ACGT) ? __shfl(nn[u], i) : nonn[rl];
         const size_t tile_abs = (size_t)tile_first + (size_t)(rl >> 6);
         int Si[6], mi;
         n_demand++;
@@ -926,14 +1004,19 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
         }
         const bool accept = (mi < T) && (!full || lex_better(Si, W));     // src/nearest.c:488-496 + heap_insert :93-117
         if (!accept) { mask &= mask - 1; continue; }
-        if (lane == 0) {
+        {
           const long long ord = ord_base + (rl - r_begin);
-          int *e = h + (full ? 1 : n + 1) * HEAP_ENTRY;
+          const int slot = full ? 1 : n + 1;
+          if (lane < HEAP_ENTRY) {
+            int v = (int)(unsigned)(ord & 0xffffffffll);
+            if (lane == 7) v = (int)(ord >> 32);
 #pragma unroll
-          for (int s = 0; s < 6; s++) e[s] = Si[s];
-          e[6] = (int)(unsigned)(ord & 0xffffffffll); e[7] = (int)(ord >> 32);
-          if (full) heap_sift_down(h, n, 1); else heap_sift_up(h, n + 1);
-          entered[rl] = 1;
+            for (int s = 0; s < 6; s++) if (lane == s) v = Si[s];
+            h[slot * HEAP_ENTRY + lane] = v;
+          }
+          if (lane == 0) entered[rl] = 1;
+          __syncthreads();
+          if (full) wave_sift_down(h, n, 1, lane); else wave_sift_up(h, n + 1, lane);
         }
         if (!full) n++;
         dirty = true; n_admit++;
@@ -1059,7 +1142,7 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
   return 0;
 }
 
-int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream = nullptr)
+int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream = nullptr)
 {
   if (n_tiles <= 0) return 0;
   if (!stream) stream = c->stream;
@@ -1081,7 +1164,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int
     if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, stream)); ev.bytes = bytes; c->evts.push_back(ev); }
     return 0;
   }
-#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles)
+#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0)
   if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan2_acgt_kernel, 8); break; case 32: LAUNCH(scan2_acgt_kernel, 32); break; default: LAUNCH(scan2_acgt_kernel, 16); } }
   else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
 #undef LAUNCH
@@ -1121,8 +1204,10 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   }
   const int ppad = n_tiles * 64;
   hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap);
-  if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
-  else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  if (c->n_idx_c > 0) {   // with no constant-and-complete column every pre-score counter is zero (common: gappy query sets)
+    if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+    else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  }
   HIPCHK(c, hipGetLastError());
   const double bytes = (double)(r_end - r_begin) * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
@@ -1133,12 +1218,13 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
     else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
   } else {
-    int rc = launch_scan2(c, tiles, tile_first, n_tiles, c->d_cnt2, ppad, bytes);
+    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes);
     if (rc) return rc;
-    if (c->acgt) hipLaunchKernelGGL((replay2_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base,
-                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
-    else         hipLaunchKernelGGL((replay2_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base,
-                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats)
+    if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
+    else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
+#undef REPLAY2
   }
   HIPCHK(c, hipGetLastError());
   c->last_tiles = tiles; c->last_nonn = nonn_tile0; c->last_n = r_end - r_begin; c->last_rbegin = r_begin; c->last_ppad = ppad;
@@ -1148,7 +1234,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
 
 // stage + pack n_ref rows (either scattered pointers or one pitched block) into `tiles` starting at slot0
 int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t rows_pitch, const int *non_n, int n_ref,
-              uint4 *tiles, int *nonn_dev, int *amb_dev, long long slot0)
+              uint4 *tiles, int *nonn_dev, int *amb_dev, int *tot_dev, long long slot0)
 {
   for (int done = 0; done < n_ref; done += PACK_CHUNK) {
     const int m = std::min(PACK_CHUNK, n_ref - done);
@@ -1161,8 +1247,8 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
     const long long s0 = slot0 + done, t0 = s0 / 64, t1 = (s0 + m - 1) / 64;
     const int nblk = (int)(t1 - t0 + 1);
     int *nn_out = non_n ? nullptr : nonn_dev;
-    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, (int *)nullptr, c->d_err);
-    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, amb_dev, c->d_err);
+    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, (int *)nullptr, tot_dev, c->d_err);
+    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, amb_dev, tot_dev, c->d_err);
     HIPCHK(c, hipGetLastError());
     if (non_n) HIPCHK(c, hipMemcpyAsync(nonn_dev + s0, non_n + done, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // h_stage is reused by the next round
@@ -1190,7 +1276,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+  void *dev[] = {c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -1216,7 +1302,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
 
   uvaia_gpu_ctx *c = new uvaia_gpu_ctx();
   c->device = device;
-  c->nq = q->n_query; c->nchar = q->nchar; c->acgt = q->acgt ? 1 : 0; c->trim = q->trim;
+  c->nq = q->n_query; c->nchar = q->nchar; c->acgt = q->acgt ? 1 : 0; c->trim = q->trim; c->n_idx_c = q->n_idx_c;
   c->P = c->acgt ? 3 : 4; c->NQ = c->acgt ? 4 : 6;
   c->W = (c->nchar + 31) / 32; c->W4 = (c->W + 3) / 4;
   c->k = heap_size < 2 ? 2 : heap_size;                      // src/min_heap.c:58
@@ -1233,7 +1319,13 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   if ((size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) > 160 * 1024) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "nbest=%d does not fit the per-query LDS heap (max 5119)", heap_size); }
 
 #define OPENCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int code_ = fail(nullptr, e_ == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); uvaia_gpu_close(c); return code_; } } while (0)
-  OPENCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {  // the gate/replay stream outranks the scan stream: its few waves sit on the critical path of the state chain
+    int prio_least = 0, prio_greatest = 0;
+    OPENCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    OPENCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
+    OPENCHK(hipStreamCreateWithPriority(&c->scan_stream, hipStreamNonBlocking, prio_least));
+    for (int i = 0; i < 2; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
+  }
   uint8_t code_tab[256]; fill_code_table(code_tab);
   OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
 
@@ -1308,6 +1400,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_batch, 0, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
   OPENCHK(hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
+  OPENCHK(hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_STRIDE * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_STRIDE * sizeof(int)));
   if (!c->fullscan) OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
@@ -1315,6 +1409,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMalloc(&c->d_rt, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_tr, c->pool_pad * sizeof(int4)));
+  OPENCHK(hipMemset(c->d_rt, 0, c->pool_pad * sizeof(int4)));      // stay zero when idx_c is empty (the pre-score is skipped)
+  OPENCHK(hipMemset(c->d_tr, 0, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_entered, c->pool_pad)); c->entered_cap = c->pool_pad;
   OPENCHK(hipMemset(c->d_entered, 0, c->pool_pad));
   OPENCHK(hipMalloc(&c->d_stage, (size_t)PACK_CHUNK * c->pitch));
@@ -1324,6 +1420,10 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   if (lds > 64 * 1024) {
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
 #undef OPENCHK
   int rc = uvaia_gpu_reset(c);
@@ -1363,7 +1463,7 @@ int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, i
   if (n_ref < 0 || (n_ref > 0 && !seq)) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
   if (n_ref == 0) return 0;
-  int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, 0);
+  int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
   const int n_tiles = (n_ref + 63) / 64;
   HIPCHK(c, hipMemsetAsync(c->d_entered, 0, (size_t)n_tiles * 64, c->stream));
@@ -1396,12 +1496,14 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   if (!c) return UVAIA_GPU_EINVAL;
   if (cap <= c->db_cap) return 0;
   if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "reserve the database before appending to it");
-  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); c->d_db = nullptr; c->d_db_nonn = nullptr; c->d_db_amb = nullptr; }
+  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); hipFree(c->d_db_tot); c->d_db = nullptr; c->d_db_nonn = nullptr; c->d_db_amb = nullptr; c->d_db_tot = nullptr; }
   const size_t tiles = (cap + 63) / 64 + 1, tile_u4 = (size_t)c->W4 * c->P * 64;
   HIPCHK(c, hipMalloc(&c->d_db, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMemset(c->d_db, 0, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_nonn, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_db_tot, tiles * 64 * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_db_tot, 0, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_amb, tiles * 64 * AMB_STRIDE * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_amb, 0, tiles * 64 * AMB_STRIDE * sizeof(int)));
   c->db_cap = tiles * 64 - 64;
@@ -1422,7 +1524,7 @@ static int db_append_common(uvaia_gpu_ctx *c, const char *const *seq, const char
     if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "database capacity %zu exceeded: call uvaia_gpu_db_reserve first", c->db_cap);
     int rc = uvaia_gpu_db_reserve(c, (size_t)n_ref); if (rc) return rc;
   }
-  int rc = pack_rows(c, seq, rows, pitch, non_n, n_ref, c->d_db, c->d_db_nonn, c->d_db_amb, (long long)c->db_n);
+  int rc = pack_rows(c, seq, rows, pitch, non_n, n_ref, c->d_db, c->d_db_nonn, c->d_db_amb, c->d_db_tot, (long long)c->db_n);
   if (rc) return rc;
   c->db_n += (size_t)n_ref;
   return 0;
@@ -1565,10 +1667,6 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   if (!c || buf < 0 || buf > 1) return UVAIA_GPU_EINVAL;
   if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "ring mode needs the two-counter scan");
   if (first + n > c->db_n || n > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database or above max_pool", first, n);
-  if (!c->scan_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
-  }
   if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
   if (buf == 1 && !c->d_cnt2b) HIPCHK(c, hipMalloc(&c->d_cnt2b, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
   const long long tf = (long long)(first / 64);
@@ -1576,7 +1674,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   c->slice_tf[buf] = tf; c->slice_tiles[buf] = n_tiles;
   c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  int rc = launch_scan2(c, c->d_db, tf, n_tiles, buf ? c->d_cnt2b : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream);
+  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cnt2b : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->scan_done[buf], c->scan_stream));
   return 0;
@@ -1594,16 +1692,19 @@ int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stri
   if (re <= rb) return 0;
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->scan_done[buf], 0));
   const int ppad = n_tiles * 64;
-  if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
-  else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  if (c->n_idx_c > 0) {
+    if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+    else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   const int2 *cnt = buf ? c->d_cnt2b : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_STRIDE;
   uint8_t *ent = c->d_entered + tf * 64;
-  if (c->acgt) hipLaunchKernelGGL((replay2_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0,
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
-  else         hipLaunchKernelGGL((replay2_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0,
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats);
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats)
+  if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
+  else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
+#undef REPLAY2
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->replay_done[buf], c->stream));
   c->replay_recorded[buf] = true;
@@ -1626,7 +1727,7 @@ int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radi
   if (n_ref < 0 || (n_ref > 0 && (!seq || !mindist))) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
   if (n_ref == 0) return 0;
-  int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, 0);
+  int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
   const int n_tiles = (n_ref + 63) / 64, ppad = n_tiles * 64;
   rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;

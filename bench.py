@@ -100,16 +100,18 @@ def main():
     load_s = time.time() - t0
     bytes_per_ref = eng.packed_bytes_per_ref()
     on_gpu = backend == "nccl"
-    comm = ring.TorchComm(dist, cuda=on_gpu) if dist is not None else None
+    comm = ring.TorchRingComm(dist, rank, world, cuda=on_gpu) if dist is not None else None
     nbytes = eng.state_bytes()
+    cons = len(pq.idx_c) > 0
 
     # ---- timed region
     def step():
         eng.reset()
         if world == 1:
             eng.search_resident(pool, ordinal0=0, want_entered=False)
-        else:   # scans run concurrently on all ranks; the heap state visits the ranks in stream order over RCCL send/recv
-            ring.run_ring(eng, comm, rank, world, slices, lambda: ring.TorchStateBuffer(nbytes, "cuda" if on_gpu else "cpu"))
+        else:   # scans run concurrently on all ranks; the heap state visits the ranks in stream order, pipelined by query group
+            ring.run_ring_grouped(eng, comm, rank, world, slices, pq.ntax, cons,
+                                  lambda nb: ring.TorchStateBuffer(nb, "cuda" if on_gpu else "cpu"))
         eng.sync()
 
     for _ in range(args.warmup):
@@ -195,7 +197,7 @@ def main():
             "metric": "ref-seqs scored/sec", "value": round(value, 2), "unit": "ref-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "multi_gpu": None if world == 1 else "block-cyclic slices of %d refs, concurrent scans, heap state (%d B) passed rank to rank per slice (RCCL send/recv), exact" % (pool, nbytes),
+            "multi_gpu": None if world == 1 else "block-cyclic slices of %d refs, concurrent scans, heap state (%d B in %d per-query-group blobs) pipelined rank to rank (RCCL isend/irecv), exact" % (pool, nbytes, world),
             "dtype": "u32 bit-planes / int32 counts", "data": "synthetic (seed %d, preset %d)" % (args.seed, args.preset),
             "config": {"workload": "BASELINE config[1]: %d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d"
                                    % (pq.ntax, args.refs, args.nchar, "4-bit IUPAC planes" if args.mode == "iupac" else "2-bit + validity planes (--acgt)", args.nbest, pool),

@@ -119,6 +119,14 @@ int uvaia_gpu_state_export (uvaia_gpu_ctx *ctx, void *dst);          /* device o
 int uvaia_gpu_state_import (uvaia_gpu_ctx *ctx, const void *src);    /* ordered before later replays */
 int uvaia_gpu_slice_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, int buf);
 int uvaia_gpu_slice_replay (uvaia_gpu_ctx *ctx, int buf, int64_t ordinal0, int stripe_start);
+/* The per-query machines are independent, so the state can travel in several blobs, one per contiguous group of queries
+ * [q0,q1): while one rank replays group j of a slice the next rank already replays group j-1 of its own slice.
+ * take_snapshot: only on the rank that opens a stripe, once it holds the state of ALL queries (the snapshot is a maximum
+ * over every query); it is a no-op for the results when the query set has no constant-and-complete column (n_idx_c == 0). */
+size_t uvaia_gpu_state_range_bytes (const uvaia_gpu_ctx *ctx, int q0, int q1);
+int uvaia_gpu_state_export_range (uvaia_gpu_ctx *ctx, void *dst, int q0, int q1);
+int uvaia_gpu_state_import_range (uvaia_gpu_ctx *ctx, const void *src, int q0, int q1);
+int uvaia_gpu_slice_replay_range (uvaia_gpu_ctx *ctx, int buf, int64_t ordinal0, int q0, int q1, int take_snapshot);
 int uvaia_gpu_entered_flags (uvaia_gpu_ctx *ctx, uint8_t *out, int clear);   /* db_size bytes; see uvaia_gpu_search_resident */
 
 /* ---- radius search: replaces the loop of src/ball.c:248-251 (seq_ball_against_query_structure,

@@ -608,6 +608,32 @@ orc_search_process_slice (orc_search *s, int n, const char *const *seqs, const c
   return 0;
 }
 
+/* the same for queries [q0,q1) only (the per-query machines are independent): used by the query-group pipelined ring */
+int
+orc_search_process_slice_range (orc_search *s, int n, const char *const *seqs, const char *const *names, const int64_t *ordinals, int snapshot, int q0, int q1)
+{
+  if (n > s->pool || s->fill || snapshot < 0) return -1;
+  for (int i = 0; i < n; i++) {
+    s->non_n[i] = orc_count_non_N (seqs[i], (size_t) s->q->nchar);
+    s->seq[i] = (char *) seqs[i];          /* borrowed for the duration of the call */
+    s->name[i] = (char *) (names ? names[i] : "");
+    s->ordinal[i] = ordinals[i];
+  }
+  s->max_incompatible = s->last_snapshot = snapshot;
+  for (int c = 0; c < n; c++) consensus_score (s, c);
+  for (int j = q0; j < q1; j++) for (int c = 0; c < n; c++) { if (s->acgt) update_heap_acgt (s, j, c); else update_heap_full (s, j, c); }
+  for (int i = 0; i < n; i++) { s->seq[i] = NULL; s->name[i] = NULL; }
+  return 0;
+}
+
+int
+orc_search_max_T (const orc_search *s)
+{ /* what the next batch's snapshot would be (src/nearest.c:290-291) */
+  int m = s->heap[0]->max_incompatible;
+  for (int j = 1; j < s->n_query; j++) if (m < s->heap[j]->max_incompatible) m = s->heap[j]->max_incompatible;
+  return m;
+}
+
 int orc_search_last_snapshot (const orc_search *s) { return s->last_snapshot; }
 
 size_t
@@ -618,12 +644,12 @@ orc_search_state_ints (const orc_search *s)
 }
 
 void
-orc_search_get_state (const orc_search *s, int *blob)
+orc_search_get_state_range (const orc_search *s, int *blob, int q0, int q1)
 {
   size_t per_q = 2 + (size_t) (s->heap[0]->heap_size + 1) * 8;
   blob[0] = s->last_snapshot;
-  for (int q = 0; q < s->n_query; q++) {
-    int *b = blob + 1 + per_q * (size_t) q;
+  for (int q = q0; q < q1; q++) {
+    int *b = blob + 1 + per_q * (size_t) (q - q0);
     const orc_heap *h = s->heap[q];
     b[0] = h->n; b[1] = h->max_incompatible;
     for (int e = 0; e <= h->heap_size; e++) {
@@ -634,14 +660,16 @@ orc_search_get_state (const orc_search *s, int *blob)
   }
 }
 
+void orc_search_get_state (const orc_search *s, int *blob) { orc_search_get_state_range (s, blob, 0, s->n_query); }
+
 void
-orc_search_set_state (orc_search *s, const int *blob, const char *name_prefix)
+orc_search_set_state_range (orc_search *s, const int *blob, const char *name_prefix, int q0, int q1)
 {
   size_t per_q = 2 + (size_t) (s->heap[0]->heap_size + 1) * 8;
   char buf[64];
   s->last_snapshot = blob[0];
-  for (int q = 0; q < s->n_query; q++) {
-    const int *b = blob + 1 + per_q * (size_t) q;
+  for (int q = q0; q < q1; q++) {
+    const int *b = blob + 1 + per_q * (size_t) (q - q0);
     orc_heap *h = s->heap[q];
     h->n = b[0]; h->max_incompatible = b[1];
     for (int e = 0; e <= h->heap_size; e++) {
@@ -652,6 +680,8 @@ orc_search_set_state (orc_search *s, const int *blob, const char *name_prefix)
     }
   }
 }
+
+void orc_search_set_state (orc_search *s, const int *blob, const char *name_prefix) { orc_search_set_state_range (s, blob, name_prefix, 0, s->n_query); }
 
 void
 orc_search_end_of_file (orc_search *s)

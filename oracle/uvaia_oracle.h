@@ -108,6 +108,10 @@ int  orc_search_feed (orc_search *s, int n, const char *const *seqs, const char 
 void orc_search_end_of_file (orc_search *s);   /* boundary between two -r files */
 /* multi-rank ring protocol tests only: one slice of a stripe as a batch with the stripe's snapshot (<0: from own state) */
 int  orc_search_process_slice (orc_search *s, int n, const char *const *seqs, const char *const *names, const int64_t *ordinals, int snapshot);
+int  orc_search_process_slice_range (orc_search *s, int n, const char *const *seqs, const char *const *names, const int64_t *ordinals, int snapshot, int q0, int q1);
+int  orc_search_max_T (const orc_search *s);
+void orc_search_get_state_range (const orc_search *s, int *blob, int q0, int q1);
+void orc_search_set_state_range (orc_search *s, const int *blob, const char *name_prefix, int q0, int q1);
 int  orc_search_last_snapshot (const orc_search *s);
 size_t orc_search_state_ints (const orc_search *s);
 void orc_search_get_state (const orc_search *s, int *blob);

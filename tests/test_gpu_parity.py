@@ -265,6 +265,14 @@ def test_ring_mode_with_several_contexts_on_one_gpu(synth, acgt, world, slice_si
                 self.arr = np.zeros(nbytes, dtype=np.uint8); self.ptr = self.arr.ctypes.data
         last = ring.run_ring_in_one_process(engines, layouts, lambda: HostBlob(engines[0].state_bytes()))
         n, T, sc, od = last.drain()
+        first_result = (n.copy(), T.copy(), sc.copy(), od.copy())
+        # and the query-group pipelined variant of the protocol gives the same final state
+        for e in engines:
+            e.reset()
+        last = ring.run_ring_grouped_in_one_process(engines, layouts, q.ntax, len(q.idx_c) > 0, lambda nbytes: HostBlob(nbytes))
+        n, T, sc, od = last.drain()
+        for x, y in zip(first_result, (n, T, sc, od)):
+            assert np.array_equal(x, y)
         rows = capi.finalise_heaps(n, sc, od)
         for iq in range(q.ntax):
             assert rows[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]]

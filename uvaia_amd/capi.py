@@ -17,7 +17,8 @@ SYMBOLS = [
     "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball",
     "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
-    "uvaia_gpu_entered_flags", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
+    "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
+    "uvaia_gpu_slice_replay_range", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
 ]
 
 
@@ -90,6 +91,10 @@ def load_library():
         "uvaia_gpu_slice_scan": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int]),
         "uvaia_gpu_slice_replay": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int]),
         "uvaia_gpu_entered_flags": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_int]),
+        "uvaia_gpu_state_range_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
+        "uvaia_gpu_state_export_range": (C.c_int, [vp, C.c_void_p, C.c_int, C.c_int]),
+        "uvaia_gpu_state_import_range": (C.c_int, [vp, C.c_void_p, C.c_int, C.c_int]),
+        "uvaia_gpu_slice_replay_range": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
         "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
     }
@@ -242,6 +247,18 @@ class Engine:
 
     def slice_replay(self, buf, ordinal0, stripe_start):
         self._chk(self.L.uvaia_gpu_slice_replay(self.ctx, int(buf), int(ordinal0), int(bool(stripe_start))))
+
+    def state_range_bytes(self, q0, q1):
+        return self.L.uvaia_gpu_state_range_bytes(self.ctx, int(q0), int(q1))
+
+    def state_export_range(self, ptr, q0, q1):
+        self._chk(self.L.uvaia_gpu_state_export_range(self.ctx, C.c_void_p(ptr), int(q0), int(q1)))
+
+    def state_import_range(self, ptr, q0, q1):
+        self._chk(self.L.uvaia_gpu_state_import_range(self.ctx, C.c_void_p(ptr), int(q0), int(q1)))
+
+    def slice_replay_range(self, buf, ordinal0, q0, q1, take_snapshot):
+        self._chk(self.L.uvaia_gpu_slice_replay_range(self.ctx, int(buf), int(ordinal0), int(q0), int(q1), int(bool(take_snapshot))))
 
     def entered_flags(self, clear=False):
         ent = np.zeros(self.db_size(), dtype=np.uint8)

@@ -64,7 +64,7 @@ struct uvaia_gpu_ctx {
   hipStream_t stream = nullptr;
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
   hipEvent_t scan_done[2] = {nullptr, nullptr}, replay_done[2] = {nullptr, nullptr};
-  bool replay_recorded[2] = {false, false};
+  bool replay_recorded[2] = {false, false}, slice_scanned[2] = {false, false}, slice_cons_done[2] = {false, false};
   int2 *d_cnt2b = nullptr;                // second counter buffer (ring mode, allocated on first use)
   int slice_tiles[2] = {0, 0}, slice_rb[2] = {0, 0}, slice_re[2] = {0, 0};
   long long slice_tf[2] = {0, 0};
@@ -909,12 +909,12 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
                                                       const int *__restrict__ snap_ptr, uint8_t *__restrict__ entered, int k,
                                                       const uint4 *__restrict__ db, long long tile_first, int W4,
                                                       const uint32_t *__restrict__ qfull, const int *__restrict__ amb_q,
-                                                      unsigned long long *__restrict__ stats)
+                                                      unsigned long long *__restrict__ stats, int q_first)
 {
   extern __shared__ int h[];
   constexpr int U = 4;
   __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
-  const int q = blockIdx.x, lane = threadIdx.x;
+  const int q = blockIdx.x + q_first, lane = threadIdx.x;
   int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
   int n = n_g[q], T = T_g[q];
   const int snap = *snap_ptr;
@@ -1221,7 +1221,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes);
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
-                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats)
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1268,6 +1268,7 @@ extern "C" {
 
 int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf);
 int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start);
+size_t uvaia_gpu_state_range_bytes(const uvaia_gpu_ctx *c, int q0, int q1);
 
 const char *uvaia_gpu_last_error(const uvaia_gpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_error.c_str(); }
 
@@ -1438,6 +1439,7 @@ int uvaia_gpu_reset(uvaia_gpu_ctx *c)
   HIPCHK(c, hipMemsetAsync(c->d_heap, 0, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), c->stream));
   hipLaunchKernelGGL(init_state_kernel, dim3((c->nq + 255) / 256), dim3(256), 0, c->stream, c->d_T, c->d_n, c->nq, c->nchar);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->d_snap, &c->nchar, sizeof(int), hipMemcpyHostToDevice, c->stream));   // cq->max_incompatible = n_sites (src/nearest.c:375)
   if (c->d_entered && c->db_n) HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
   if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1633,33 +1635,45 @@ int uvaia_gpu_replay_stats(uvaia_gpu_ctx *c, unsigned long long out[3], int rese
 // ---- ring mode (multi-GPU, DESIGN.md "Multi-GPU"): the database is dealt block-cyclically, every rank scans its slice
 // of a stripe concurrently, and the small per-query state travels rank to rank so that each query still sees the
 // references in stream order.  state blob = snapshot, n[q], T[q], heap[q][k+1][8]  (all int32).
-size_t uvaia_gpu_state_bytes(const uvaia_gpu_ctx *c)
+size_t uvaia_gpu_state_range_bytes(const uvaia_gpu_ctx *c, int q0, int q1)
 {
-  return c ? sizeof(int) * (4 + 2 * (size_t)c->nq + (size_t)c->nq * (c->k + 1) * HEAP_ENTRY) : 0;
+  if (!c || q0 < 0 || q1 > c->nq || q1 < q0) return 0;
+  const size_t nqr = (size_t)(q1 - q0);
+  return sizeof(int) * (4 + 2 * nqr + nqr * (c->k + 1) * HEAP_ENTRY);
 }
+size_t uvaia_gpu_state_bytes(const uvaia_gpu_ctx *c) { return c ? uvaia_gpu_state_range_bytes(c, 0, c->nq) : 0; }
 
-int uvaia_gpu_state_export(uvaia_gpu_ctx *c, void *dst)
-{ // dst: device (or pinned host) memory of uvaia_gpu_state_bytes(); ordered on the replay stream, then waited for
-  if (!c || !dst) return UVAIA_GPU_EINVAL;
+int uvaia_gpu_state_export_range(uvaia_gpu_ctx *c, void *dst, int q0, int q1)
+{ // dst: device (or host) memory of uvaia_gpu_state_range_bytes(); ordered on the replay stream, then waited for
+  if (!c || !dst || q0 < 0 || q1 > c->nq || q1 < q0) return UVAIA_GPU_EINVAL;
   int *d = (int *)dst;
+  const size_t nqr = (size_t)(q1 - q0), he = (size_t)(c->k + 1) * HEAP_ENTRY;
   HIPCHK(c, hipMemcpyAsync(d, c->d_snap, sizeof(int), hipMemcpyDefault, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + 4, c->d_n, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + 4 + c->nq, c->d_T, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + 4 + 2 * (size_t)c->nq, c->d_heap, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), hipMemcpyDefault, c->stream));
+  if (nqr) {
+    HIPCHK(c, hipMemcpyAsync(d + 4, c->d_n + q0, nqr * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 4 + nqr, c->d_T + q0, nqr * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 4 + 2 * nqr, c->d_heap + (size_t)q0 * he, nqr * he * sizeof(int), hipMemcpyDefault, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 
-int uvaia_gpu_state_import(uvaia_gpu_ctx *c, const void *src)
+int uvaia_gpu_state_import_range(uvaia_gpu_ctx *c, const void *src, int q0, int q1)
 {
-  if (!c || !src) return UVAIA_GPU_EINVAL;
+  if (!c || !src || q0 < 0 || q1 > c->nq || q1 < q0) return UVAIA_GPU_EINVAL;
   const int *d = (const int *)src;
+  const size_t nqr = (size_t)(q1 - q0), he = (size_t)(c->k + 1) * HEAP_ENTRY;
   HIPCHK(c, hipMemcpyAsync(c->d_snap, d, sizeof(int), hipMemcpyDefault, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_n, d + 4, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_T, d + 4 + c->nq, (size_t)c->nq * sizeof(int), hipMemcpyDefault, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_heap, d + 4 + 2 * (size_t)c->nq, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int), hipMemcpyDefault, c->stream));
+  if (nqr) {
+    HIPCHK(c, hipMemcpyAsync(c->d_n + q0, d + 4, nqr * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_T + q0, d + 4 + nqr, nqr * sizeof(int), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_heap + (size_t)q0 * he, d + 4 + 2 * nqr, nqr * he * sizeof(int), hipMemcpyDefault, c->stream));
+  }
   return 0;
 }
+
+int uvaia_gpu_state_export(uvaia_gpu_ctx *c, void *dst) { return c ? uvaia_gpu_state_export_range(c, dst, 0, c->nq) : UVAIA_GPU_EINVAL; }
+int uvaia_gpu_state_import(uvaia_gpu_ctx *c, const void *src) { return c ? uvaia_gpu_state_import_range(c, src, 0, c->nq) : UVAIA_GPU_EINVAL; }
 
 // counts of database references [first, first+n) into counter buffer `buf` (0/1), asynchronously on the scan stream
 int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
@@ -1667,12 +1681,13 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   if (!c || buf < 0 || buf > 1) return UVAIA_GPU_EINVAL;
   if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "ring mode needs the two-counter scan");
   if (first + n > c->db_n || n > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database or above max_pool", first, n);
-  if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
   if (buf == 1 && !c->d_cnt2b) HIPCHK(c, hipMalloc(&c->d_cnt2b, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
   const long long tf = (long long)(first / 64);
   const int n_tiles = n ? (int)((first + n + 63) / 64 - first / 64) : 0;
   c->slice_tf[buf] = tf; c->slice_tiles[buf] = n_tiles;
   c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
+  c->slice_scanned[buf] = true; c->slice_cons_done[buf] = false;
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
   int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cnt2b : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream);
   if (rc) return rc;
@@ -1680,28 +1695,31 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   return 0;
 }
 
-// gate + heaps over the slice scanned into `buf`, from the state currently held (imported or local).
-// stripe_start != 0: this slice opens a batch, so the batch snapshot (cq->max_incompatible, src/nearest.c:290-291) is
-// taken from the current state; otherwise the imported snapshot of the stripe is used.
-int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start)
+// gate + heaps of queries [q0,q1) over the slice scanned into `buf`, from the state currently held (imported or local).
+// take_snapshot != 0: this call opens a batch for the whole query set, so the batch snapshot (cq->max_incompatible,
+// src/nearest.c:290-291) is taken from the state of ALL queries now held; otherwise the imported snapshot is used.
+int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int q0, int q1, int take_snapshot)
 {
-  if (!c || buf < 0 || buf > 1 || !c->scan_stream) return c ? fail(c, UVAIA_GPU_ESTATE, "slice_replay without slice_scan") : UVAIA_GPU_EINVAL;
+  if (!c || buf < 0 || buf > 1) return UVAIA_GPU_EINVAL;
+  if (!c->slice_scanned[buf]) return fail(c, UVAIA_GPU_ESTATE, "slice_replay without slice_scan");
+  if (q0 < 0 || q1 > c->nq || q1 < q0) return fail(c, UVAIA_GPU_EINVAL, "bad query range [%d,%d)", q0, q1);
   const int n_tiles = c->slice_tiles[buf], rb = c->slice_rb[buf], re = c->slice_re[buf];
   const long long tf = c->slice_tf[buf];
-  if (stripe_start) hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap);
-  if (re <= rb) return 0;
+  if (take_snapshot) { hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap); c->slice_cons_done[buf] = false; }
+  if (re <= rb || q1 == q0) return 0;
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->scan_done[buf], 0));
   const int ppad = n_tiles * 64;
-  if (c->n_idx_c > 0) {
+  if (c->n_idx_c > 0 && !c->slice_cons_done[buf]) {     // once per slice: the pre-score does not depend on the query
     if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
     else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+    c->slice_cons_done[buf] = true;
   }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   const int2 *cnt = buf ? c->d_cnt2b : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_STRIDE;
   uint8_t *ent = c->d_entered + tf * 64;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats)
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1711,6 +1729,9 @@ int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stri
   c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf;
   return 0;
 }
+
+int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start)
+{ return c ? uvaia_gpu_slice_replay_range(c, buf, ordinal0, 0, c->nq, stripe_start) : UVAIA_GPU_EINVAL; }
 
 int uvaia_gpu_entered_flags(uvaia_gpu_ctx *c, uint8_t *out, int clear)
 { // "entered any heap" flags of the resident database accumulated by slice replays (and by search_resident)

@@ -114,3 +114,112 @@ def run_ring_in_one_process(engines, slices_per_rank, alloc_state):
                 engines[r].state_export(state.ptr)
                 have_state = True
     return engines[-1]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Query-group pipelined ring.  The per-query machines are independent, so the state travels as `world` blobs (one per
+# contiguous group of queries).  While rank r replays group j of its slice, rank r+1 replays group j-1 of its own slice:
+# every hop carries 1/world of the replay work and, after a fill of world-1 hops, all ranks replay concurrently.
+# The only coupling between queries is the batch snapshot (max tolerance over ALL queries at stripe start, reference
+# src/nearest.c:290-291), which matters only if the query set has constant-and-complete columns (`cons`): then rank 0
+# waits for every group of the previous stripe before it opens the next one.
+# ----------------------------------------------------------------------------------------------------------------------
+def query_groups(n_query, world):
+    b = [n_query * j // world for j in range(world + 1)]
+    return [(b[j], b[j + 1]) for j in range(world)]
+
+
+class TorchRingComm:
+    """Non-blocking point-to-point transport.  The wrap-around link (last rank -> rank 0) uses its own process group so that,
+    whatever the backend serialises per communicator, a rank's sends never queue behind its own pre-posted receives."""
+
+    def __init__(self, dist, rank, world, cuda):
+        self.dist, self.rank, self.world, self.cuda = dist, rank, world, cuda
+        self.fwd = dist.new_group(list(range(world)))
+        self.wrap = dist.new_group(list(range(world)))
+
+    def _group(self, src, dst):
+        return self.wrap if (src == self.world - 1 and dst == 0) else self.fwd
+
+    def irecv(self, buf, src):
+        return self.dist.irecv(buf.tensor, src, group=self._group(src, self.rank))
+
+    def isend(self, buf, dst):
+        return self.dist.isend(buf.tensor, dst, group=self._group(self.rank, dst))
+
+    def wait(self, work):
+        work.wait()
+        if self.cuda:
+            import torch
+            torch.cuda.current_stream().synchronize()       # the engine's streams are not torch's: order through the host
+
+
+def run_ring_grouped(engine, comm, rank, world, slices, n_query, cons, make_buffer):
+    """All stripes on one rank, state in `world` per-query-group blobs.  make_buffer(nbytes) -> object with .tensor/.ptr.
+    Returns True on the rank that ends up holding the final heaps (world-1)."""
+    groups = query_groups(n_query, world)
+    n = len(slices)
+    if n == 0:
+        return rank == world - 1
+    src, dst = (rank - 1) % world, (rank + 1) % world
+    recv = {}
+    for s in range(n):                                   # every receive is posted up front, in the order the peer sends
+        for j, (q0, q1) in enumerate(groups):
+            if rank == 0 and s == 0:
+                continue
+            buf = make_buffer(engine.state_range_bytes(q0, q1))
+            recv[(s, j)] = (buf, comm.irecv(buf, src))
+    sends = []
+    engine.slice_scan(slices[0].first, slices[0].n, 0)
+    for s in range(n):
+        if s + 1 < n:
+            engine.slice_scan(slices[s + 1].first, slices[s + 1].n, (s + 1) & 1)
+        gather_first = (rank == 0 and s > 0 and cons)      # the snapshot needs the tolerance of every query
+        if gather_first:
+            for j, (q0, q1) in enumerate(groups):
+                buf, work = recv[(s, j)]
+                comm.wait(work)
+                engine.state_import_range(buf.ptr, q0, q1)
+        for j, (q0, q1) in enumerate(groups):
+            if (s, j) in recv and not gather_first:
+                buf, work = recv[(s, j)]
+                comm.wait(work)
+                engine.state_import_range(buf.ptr, q0, q1)
+            take_snapshot = (rank == 0 and j == 0 and (cons or s == 0))
+            engine.slice_replay_range(s & 1, slices[s].ordinal0, q0, q1, take_snapshot)
+            if not (rank == world - 1 and s == n - 1):
+                out = make_buffer(engine.state_range_bytes(q0, q1))
+                engine.state_export_range(out.ptr, q0, q1)
+                sends.append((out, comm.isend(out, dst)))
+    for out, work in sends:
+        work.wait()
+    return rank == world - 1
+
+
+def run_ring_grouped_in_one_process(engines, slices_per_rank, n_query, cons, make_buffer):
+    """The grouped protocol with every rank's engine driven from one process in a valid serial order (tests)."""
+    world = len(engines)
+    groups = query_groups(n_query, world)
+    n = len(slices_per_rank[0])
+    blobs = {}                                             # (stripe, receiving rank, group) -> buffer
+    for r in range(world):
+        if n:
+            engines[r].slice_scan(slices_per_rank[r][0].first, slices_per_rank[r][0].n, 0)
+    for s in range(n):
+        for r in range(world):
+            sl = slices_per_rank[r]
+            if s + 1 < n:
+                engines[r].slice_scan(sl[s + 1].first, sl[s + 1].n, (s + 1) & 1)
+            gather_first = (r == 0 and s > 0 and cons)
+            if gather_first:
+                for j, (q0, q1) in enumerate(groups):
+                    engines[r].state_import_range(blobs.pop((s, r, j)).ptr, q0, q1)
+            for j, (q0, q1) in enumerate(groups):
+                if (s, r, j) in blobs:
+                    engines[r].state_import_range(blobs.pop((s, r, j)).ptr, q0, q1)
+                engines[r].slice_replay_range(s & 1, sl[s].ordinal0, q0, q1, r == 0 and j == 0 and (cons or s == 0))
+                if not (r == world - 1 and s == n - 1):
+                    out = make_buffer(engines[r].state_range_bytes(q0, q1))
+                    engines[r].state_export_range(out.ptr, q0, q1)
+                    blobs[(s, r + 1, j) if r + 1 < world else (s + 1, 0, j)] = out
+    return engines[-1]

@@ -116,7 +116,7 @@ int uvaia_gpu_sync (uvaia_gpu_ctx *ctx);
  * single process running the same stripes as pools.  After the last stripe the last rank holds the final heaps. */
 size_t uvaia_gpu_state_bytes (const uvaia_gpu_ctx *ctx);
 int uvaia_gpu_state_export (uvaia_gpu_ctx *ctx, void *dst);          /* device or host pointer; returns when dst is complete */
-int uvaia_gpu_state_import (uvaia_gpu_ctx *ctx, const void *src);    /* ordered before later replays */
+int uvaia_gpu_state_import (uvaia_gpu_ctx *ctx, const void *src);    /* src may be reused once this returns */
 int uvaia_gpu_slice_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, int buf);
 int uvaia_gpu_slice_replay (uvaia_gpu_ctx *ctx, int buf, int64_t ordinal0, int stripe_start);
 /* The per-query machines are independent, so the state can travel in several blobs, one per contiguous group of queries

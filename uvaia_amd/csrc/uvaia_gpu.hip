@@ -916,7 +916,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
   const int q = blockIdx.x + q_first, lane = threadIdx.x;
   int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
-  int n = n_g[q], T = T_g[q];
+  int n = min(max(n_g[q], 0), k), T = T_g[q];       // clamp: an imported state blob is external input
   const int snap = *snap_ptr;
   for (int i = lane; i < (n + 1) * HEAP_ENTRY; i += 64) h[i] = hg[i];
   __syncthreads();
@@ -1669,6 +1669,7 @@ int uvaia_gpu_state_import_range(uvaia_gpu_ctx *c, const void *src, int q0, int 
     HIPCHK(c, hipMemcpyAsync(c->d_T + q0, d + 4 + nqr, nqr * sizeof(int), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_heap + (size_t)q0 * he, d + 4 + 2 * nqr, nqr * he * sizeof(int), hipMemcpyDefault, c->stream));
   }
+  HIPCHK(c, hipStreamSynchronize(c->stream));     // src may be reused or freed once this returns
   return 0;
 }
 

@@ -131,7 +131,8 @@ def query_groups(n_query, world):
 
 class TorchRingComm:
     """Non-blocking point-to-point transport.  The wrap-around link (last rank -> rank 0) uses its own process group so that,
-    whatever the backend serialises per communicator, a rank's sends never queue behind its own pre-posted receives."""
+    whatever the backend serialises per communicator, the last rank's sends and rank 0's receives never queue behind the
+    forward traffic of the same pair of ranks (world = 2)."""
 
     def __init__(self, dist, rank, world, cuda):
         self.dist, self.rank, self.world, self.cuda = dist, rank, world, cuda
@@ -162,29 +163,28 @@ def run_ring_grouped(engine, comm, rank, world, slices, n_query, cons, make_buff
     if n == 0:
         return rank == world - 1
     src, dst = (rank - 1) % world, (rank + 1) % world
-    recv = {}
-    for s in range(n):                                   # every receive is posted up front, in the order the peer sends
-        for j, (q0, q1) in enumerate(groups):
-            if rank == 0 and s == 0:
-                continue
-            buf = make_buffer(engine.state_range_bytes(q0, q1))
-            recv[(s, j)] = (buf, comm.irecv(buf, src))
+    # Receives are posted in program order, right before they are needed (never ahead of this rank's own sends): if the
+    # backend serialises all point-to-point operations of a process group on one stream, a receive posted early would
+    # hold up the sends queued behind it.  Sends are non-blocking; the wrap-around link has its own process group.
     sends = []
+
+    def receive(s, j, q0, q1):
+        buf = make_buffer(engine.state_range_bytes(q0, q1))
+        comm.wait(comm.irecv(buf, src))
+        engine.state_import_range(buf.ptr, q0, q1)
+
     engine.slice_scan(slices[0].first, slices[0].n, 0)
     for s in range(n):
         if s + 1 < n:
             engine.slice_scan(slices[s + 1].first, slices[s + 1].n, (s + 1) & 1)
+        expects = not (rank == 0 and s == 0)
         gather_first = (rank == 0 and s > 0 and cons)      # the snapshot needs the tolerance of every query
         if gather_first:
             for j, (q0, q1) in enumerate(groups):
-                buf, work = recv[(s, j)]
-                comm.wait(work)
-                engine.state_import_range(buf.ptr, q0, q1)
+                receive(s, j, q0, q1)
         for j, (q0, q1) in enumerate(groups):
-            if (s, j) in recv and not gather_first:
-                buf, work = recv[(s, j)]
-                comm.wait(work)
-                engine.state_import_range(buf.ptr, q0, q1)
+            if expects and not gather_first:
+                receive(s, j, q0, q1)
             take_snapshot = (rank == 0 and j == 0 and (cons or s == 0))
             engine.slice_replay_range(s & 1, slices[s].ordinal0, q0, q1, take_snapshot)
             if not (rank == world - 1 and s == n - 1):
@@ -213,10 +213,12 @@ def run_ring_grouped_in_one_process(engines, slices_per_rank, n_query, cons, mak
             gather_first = (r == 0 and s > 0 and cons)
             if gather_first:
                 for j, (q0, q1) in enumerate(groups):
-                    engines[r].state_import_range(blobs.pop((s, r, j)).ptr, q0, q1)
+                    blob = blobs.pop((s, r, j))                 # keep a reference while the engine reads it
+                    engines[r].state_import_range(blob.ptr, q0, q1)
             for j, (q0, q1) in enumerate(groups):
                 if (s, r, j) in blobs:
-                    engines[r].state_import_range(blobs.pop((s, r, j)).ptr, q0, q1)
+                    blob = blobs.pop((s, r, j))
+                    engines[r].state_import_range(blob.ptr, q0, q1)
                 engines[r].slice_replay_range(s & 1, sl[s].ordinal0, q0, q1, r == 0 and j == 0 and (cons or s == 0))
                 if not (r == world - 1 and s == n - 1):
                     out = make_buffer(engines[r].state_range_bytes(q0, q1))

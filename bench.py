@@ -144,11 +144,11 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "kernel": ("scan_%s_kernel" % args.mode) if fullscan else ("scan2v_kernel" if os.environ.get("UVAIA_GPU_SCAN") == "lds" else "scan2_%s_kernel" % args.mode),
-        "valu_ops_per_pair_word": ops_per_pair_word,
+        "kernel": ("scan_%s_kernel" % args.mode) if fullscan else {"lds": "scan2v_kernel", "sgpr": "scan2_%s_kernel" % args.mode}.get(os.environ.get("UVAIA_GPU_SCAN", ""), "scan3_kernel"),
+        "dense_equivalent_ops_per_pair_word": ops_per_pair_word,
         "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
         "algorithmic_bytes_per_launch": scan_bytes / launches,
-        "valu_tlaneops_per_s": round(valu_rate, 2),
+        "dense_equivalent_tlaneops_per_s": round(valu_rate, 2),
         "note": "at %d resident queries the scan is integer-VALU bound, not HBM bound (DESIGN.md)" % pq.ntax,
     }
 
@@ -157,7 +157,7 @@ def main():
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["scan2_iupac_kernel"]
         same = all(pm["config"][k] == v for k, v in (("queries", pq.ntax), ("refs_per_gpu", args.refs), ("pool", pool), ("mode", args.mode)))
-        if same and not fullscan and world == 1 and os.environ.get("UVAIA_GPU_SCAN", "sgpr") != "lds":
+        if same and not fullscan and world == 1 and os.environ.get("UVAIA_GPU_SCAN", "") == pm.get("variant", "sgpr"):
             roofline["traffic"] = pm["hbm_side_read_bytes_per_launch"] + pm["write_bytes_per_launch"]
             roofline["traffic_note"] = "FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch, profiles/r01_pmc_traffic.json; L2 misses incl. Infinity-Cache hits"
     except Exception:

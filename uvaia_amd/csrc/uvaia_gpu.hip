@@ -76,7 +76,16 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qp2 = nullptr;     // [nq_pad][W4][4][4]    (lo, hi, isACGT, valid) for the two-counter scan (default mode)
   uint4 *d_qv = nullptr;         // [nq_pad/16][W4pad][16][4]  the same planes laid out for LDS staging (scan2v_kernel)
   int W4pad = 0;
-  int scan_variant = 0;          // 0 = scalar-operand scan2_*_kernel (default), 1 = LDS-broadcast scan2v_kernel (UVAIA_GPU_SCAN=lds)
+  int scan_variant = 2;          // 2 = column-compressed scan3_kernel (default); 0 = scalar-operand scan2_*_kernel, 1 = LDS-broadcast
+                                 // scan2v_kernel (UVAIA_GPU_SCAN=sgpr|lds), kept for A/B measurements
+  // column-compressed scan: classes of the alignment columns for this query set, compressed/dirty query planes, derived reference planes
+  uint32_t *d_cls = nullptr;     // [W4*4][4]  cL, cH, constMask, polyMask
+  uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][4][4]   compressed polymorphic columns of the queries (L, H, I, -)
+  uint32_t *d_qc = nullptr;      // [nq_pad][W4][4][2]    ~qI & constMask, ~qV (default) / ~qI (--acgt)
+  uint32_t *d_flags = nullptr;   // [nq_pad/16][W4][16 bytes]
+  int NP = 0, NP4 = 0;
+  uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
+  int *d_batch_tote = nullptr, *d_db_tote = nullptr;
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
@@ -469,6 +478,193 @@ __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict
   const int total = tot[r];
 #pragma unroll
   for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0], total - acc[q][1]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device: column-compressed two-counter scan (production path)
+// ------------------------------------------------------------------------------------------------------------
+// uvaia compares each reference once against a consensus of the queries on the columns where the queries agree
+// (src/nearest.c:428-433, src/fastaseq.c:744-768).  The same idea, restated for bit-planes and kept exact for every pair:
+//   * a column is CONSTANT if all queries that are ACGT there carry the same base b (queries that are N/gap/ambiguous there
+//     simply do not count), POLYMORPHIC if two queries carry different bases.
+//   * constant columns:   ACGT matches(q,r) = popc(E_r & qI) = popc(E_r) - popc(E_r & ~qI),   E_r = [r is ACGT and equals b]
+//                         (--acgt: mismatches = popc(D_r & qI), D_r = [r is ACGT and differs from b])
+//     so, exactly like the valid-pair count, only the word groups where the query is NOT ACGT cost anything;
+//   * polymorphic columns (typically 14-25 % of the alignment) are bit-gathered into contiguous words and compared densely.
+// derive_ev_kernel / gather_poly_kernel build the per-reference planes for a given query set; scan3_kernel consumes them.
+
+// one block per tile, wave v handles word groups v, v+4, ...:  ev[tile][w4][0] = E (or D with ACGT), [1] = valid (or is-ACGT)
+template <bool ACGT>
+__global__ __launch_bounds__(256) void derive_ev_kernel(const uint4 *__restrict__ tiles, long long tile_base, int W4,
+                                                         const uint32_t *__restrict__ cls /*[W4*4][4]: cL, cH, constMask, polyMask*/,
+                                                         uint4 *__restrict__ ev, int *__restrict__ tot_e)
+{
+  constexpr int P = ACGT ? 3 : 4;
+  __shared__ int partial[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long tile = tile_base + blockIdx.x;
+  const uint4 *t = tiles + (size_t)tile * W4 * P * 64 + lane;
+  uint4 *o = ev + (size_t)tile * W4 * 2 * 64 + lane;
+  int te = 0;
+  for (int w4 = wv; w4 < W4; w4 += 4) {
+    const uint4 p0 = t[(size_t)(w4 * P + 0) * 64], p1 = t[(size_t)(w4 * P + 1) * 64], p2 = t[(size_t)(w4 * P + 2) * 64], p3 = t[(size_t)(w4 * P + (P - 1)) * 64];
+    uint32_t e[4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t rL, rH, rI, rV;
+      if (ACGT) { rL = u4c(p0, j); rH = u4c(p1, j); rI = u4c(p2, j); rV = rI; }
+      else {
+        const uint32_t a = u4c(p0, j), cc = u4c(p1, j), g = u4c(p2, j), tt = u4c(p3, j);
+        const uint32_t par = a ^ cc ^ g ^ tt, three = (a & cc & (g | tt)) | (g & tt & (a | cc));
+        rI = par & ~three; rL = (cc | tt) & rI; rH = (g | tt) & rI; rV = a | cc | g | tt;
+      }
+      const uint32_t *c4 = cls + (size_t)(w4 * 4 + j) * 4;
+      const uint32_t diff = (rL ^ c4[0]) | (rH ^ c4[1]);
+      e[j] = rI & c4[2] & (ACGT ? diff : ~diff);
+      v[j] = rV;
+      te += __popc(e[j]);
+    }
+    o[(size_t)(w4 * 2 + 0) * 64] = make_uint4(e[0], e[1], e[2], e[3]);
+    o[(size_t)(w4 * 2 + 1) * 64] = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  partial[wv][lane] = te;
+  __syncthreads();
+  if (wv == 0) tot_e[tile * 64 + lane] = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+}
+
+// one wave per tile: compresses the polymorphic columns (uniform masks) of each lane's reference into NPw contiguous words
+// poly[tile][p4][plane L,H,I][lane] (uint4 = 4 consecutive compressed words)
+template <bool ACGT>
+__global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict__ tiles, long long tile_base, int W4, int NP4,
+                                                          const uint32_t *__restrict__ cls, uint4 *__restrict__ poly)
+{
+  constexpr int P = ACGT ? 3 : 4;
+  const int lane = threadIdx.x;
+  const long long tile = tile_base + blockIdx.x;
+  const uint4 *t = tiles + (size_t)tile * W4 * P * 64 + lane;
+  uint4 *o = poly + (size_t)tile * NP4 * 3 * 64 + lane;
+  unsigned long long bL = 0, bH = 0, bI = 0;     // bit staging (uniform fill level)
+  int fill = 0, ow = 0;                          // bits staged, compressed words emitted
+  uint32_t wL[4] = {0, 0, 0, 0}, wH[4] = {0, 0, 0, 0}, wI[4] = {0, 0, 0, 0};
+  auto flush_word = [&]() {
+    wL[ow & 3] = (uint32_t)bL; wH[ow & 3] = (uint32_t)bH; wI[ow & 3] = (uint32_t)bI;
+    bL >>= 32; bH >>= 32; bI >>= 32; fill -= 32;
+    if ((ow & 3) == 3) {
+      const int p4 = ow >> 2;
+      o[(size_t)(p4 * 3 + 0) * 64] = make_uint4(wL[0], wL[1], wL[2], wL[3]);
+      o[(size_t)(p4 * 3 + 1) * 64] = make_uint4(wH[0], wH[1], wH[2], wH[3]);
+      o[(size_t)(p4 * 3 + 2) * 64] = make_uint4(wI[0], wI[1], wI[2], wI[3]);
+      wL[0] = wL[1] = wL[2] = wL[3] = wH[0] = wH[1] = wH[2] = wH[3] = wI[0] = wI[1] = wI[2] = wI[3] = 0;
+    }
+    ow++;
+  };
+  for (int w4 = 0; w4 < W4; w4++) {
+    const uint32_t *c4 = cls + (size_t)w4 * 16;
+    if ((c4[3] | c4[7] | c4[11] | c4[15]) == 0u) continue;            // no polymorphic column in this group (uniform)
+    const uint4 p0 = t[(size_t)(w4 * P + 0) * 64], p1 = t[(size_t)(w4 * P + 1) * 64], p2 = t[(size_t)(w4 * P + 2) * 64], p3 = t[(size_t)(w4 * P + (P - 1)) * 64];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t m = c4[j * 4 + 3];
+      if (!m) continue;
+      uint32_t rL, rH, rI;
+      if (ACGT) { rL = u4c(p0, j); rH = u4c(p1, j); rI = u4c(p2, j); }
+      else {
+        const uint32_t a = u4c(p0, j), cc = u4c(p1, j), g = u4c(p2, j), tt = u4c(p3, j);
+        const uint32_t par = a ^ cc ^ g ^ tt, three = (a & cc & (g | tt)) | (g & tt & (a | cc));
+        rI = par & ~three; rL = (cc | tt) & rI; rH = (g | tt) & rI;
+      }
+      while (m) {                                                      // uniform loop over the polymorphic columns of the word
+        const int b = __ffs(m) - 1; m &= m - 1;
+        bL |= (unsigned long long)((rL >> b) & 1u) << fill;
+        bH |= (unsigned long long)((rH >> b) & 1u) << fill;
+        bI |= (unsigned long long)((rI >> b) & 1u) << fill;
+        if (++fill == 32) flush_word();
+      }
+    }
+  }
+  if (fill > 0) { fill = 32; flush_word(); }
+  while (ow & 3) { fill = 32; flush_word(); }                          // pad the last group with zero words
+}
+
+// scan over the derived planes: acc0 = dense count on the compressed polymorphic words, acc1/acc2 = what the query's
+// non-ACGT / invalid sites take away on the constant columns / from the valid count (dirty word groups only).
+//   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
+// flags[qtile][w4][q] : bit j = query word 4*w4+j is not all-ACGT on a constant column, bit 4+j = not all valid (ACGT)
+// qc[q][w4][j][2]     : ~qI & constMask, ~qV (default) / ~qI (--acgt)            qpl[q][p4][j][4]: compressed L, H, I
+template <int QT, bool ACGT>
+__global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
+                                                     int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ qc,
+                                                     const uint32_t *__restrict__ flags, const int *__restrict__ tot_e, const int *__restrict__ tot_v,
+                                                     int2 *__restrict__ out, int ppad, int n_qtiles)
+{
+  static_assert(QT == 16, "flag words are laid out for tiles of 16 queries");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int qtile, group;
+  if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
+  const int trel = group * 4 + wave;
+  if (trel >= n_tiles) return;
+  const int q0 = qtile * QT;
+  int acc[QT][3];
+#pragma unroll
+  for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = acc[q][2] = 0; }
+  // ---- polymorphic columns, dense
+  {
+    const uint4 *t = poly + (size_t)(tile_first + trel) * NP4 * 3 * 64 + lane;
+    const size_t qstride = (size_t)NP4 * 16;
+    const uint32_t *qb = qpl + (size_t)q0 * qstride;
+    for (int p4 = 0; p4 < NP4; p4++) {
+      const uint4 pL = t[(size_t)(p4 * 3 + 0) * 64], pH = t[(size_t)(p4 * 3 + 1) * 64], pI = t[(size_t)(p4 * 3 + 2) * 64];
+      const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
+      const uint32_t *s0 = qb + (size_t)p4 * 16;
+      QWords<16> cur, nxt;
+      load_qwords(cur, s0);
+#pragma unroll
+      for (int q = 0; q < QT; q++) {
+        if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t d = rL[j] ^ cur.v[j * 4 + 0];
+          const uint32_t y = B3(rH[j], cur.v[j * 4 + 1], d, (TT_A ^ TT_B) | TT_C);
+          acc[q][0] = bcnt_acc(ACGT ? B3(y, rI[j], cur.v[j * 4 + 2], TT_A & TT_B & TT_C) : B3(y, rI[j], cur.v[j * 4 + 2], ~TT_A & TT_B & TT_C), acc[q][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < QT) cur = nxt;
+      }
+    }
+  }
+  // ---- constant columns and validity: only where a query is dirty
+  {
+    const uint4 *t = ev + (size_t)(tile_first + trel) * W4 * 2 * 64 + lane;
+    const uint32_t *fl = flags + (size_t)qtile * W4 * 4;                 // 16 flag bytes = 4 dwords per word group
+    const size_t qstride = (size_t)W4 * 8;
+    const uint32_t *qb = qc + (size_t)q0 * qstride;
+    for (int w4 = 0; w4 < W4; w4++) {
+      const uint32_t f0 = fl[w4 * 4 + 0], f1 = fl[w4 * 4 + 1], f2 = fl[w4 * 4 + 2], f3 = fl[w4 * 4 + 3];
+      if ((f0 | f1 | f2 | f3) == 0u) continue;                           // every query of the tile is clean here
+      const uint4 pE = t[(size_t)(w4 * 2 + 0) * 64], pV = t[(size_t)(w4 * 2 + 1) * 64];
+      const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
+#pragma unroll
+      for (int q = 0; q < QT; q++) {
+        const uint32_t fw = (q < 4) ? f0 : (q < 8) ? f1 : (q < 12) ? f2 : f3;
+        const uint32_t f = (fw >> ((q & 3) * 8)) & 0xFFu;
+        if (f == 0u) continue;                                           // wave-uniform: the flags live in scalar registers
+        const uint32_t *s = qb + (size_t)q * qstride + (size_t)w4 * 8;
+        if (f & 0x0Fu) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[q][1] = bcnt_acc(rE[j] & s[j * 2 + 0], acc[q][1]);
+        }
+        if (f & 0xF0u) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[q][2] = bcnt_acc(rV[j] & s[j * 2 + 1], acc[q][2]);
+        }
+      }
+    }
+  }
+  const size_t r = (size_t)trel * 64 + lane;
+  const int te = tot_e[r], tv = tot_v[r];
+#pragma unroll
+  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0] + te - acc[q][1], tv - acc[q][2]);
 }
 
 // LDS-broadcast variant of the two-counter scan.  Measured on MI355X (profiles/r01_valu_rate_microbench.txt): a VALU
@@ -1148,12 +1344,24 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
   if (!stream) stream = c->stream;
   const int n_qtiles = (c->nq + c->qt - 1) / c->qt;
   dim3 grid(scan_grid_size(n_qtiles, (n_tiles + 3) / 4)), block(256);
-  ScanEvt ev{};
+  ScanEvt ev_{};
   if (c->profile) {
-    HIPCHK(c, hipEventCreate(&ev.a)); HIPCHK(c, hipEventCreate(&ev.b));
-    HIPCHK(c, hipEventRecord(ev.a, stream));
+    HIPCHK(c, hipEventCreate(&ev_.a)); HIPCHK(c, hipEventCreate(&ev_.b));
+    HIPCHK(c, hipEventRecord(ev_.a, stream));
   }
   const uint32_t *qp = c->acgt ? c->d_qp : c->d_qp2;
+  if (c->scan_variant == 2) {
+    const bool is_db = (tiles == c->d_db);
+    const uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
+    const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
+    const int nqt3 = (c->nq + 15) / 16;
+    dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
+    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3);
+    HIPCHK(c, hipGetLastError());
+    if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
+    return 0;
+  }
   if (c->scan_variant == 1) {
     constexpr int QTV = 16, RV = 2;
     const int nqtv = (c->nq + QTV - 1) / QTV;
@@ -1161,7 +1369,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     if (c->acgt) hipLaunchKernelGGL((scan2v_kernel<QTV, RV, true>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
     else         hipLaunchKernelGGL((scan2v_kernel<QTV, RV, false>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
     HIPCHK(c, hipGetLastError());
-    if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, stream)); ev.bytes = bytes; c->evts.push_back(ev); }
+    if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
   }
 #define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0)
@@ -1169,7 +1377,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
   else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
 #undef LAUNCH
   HIPCHK(c, hipGetLastError());
-  if (c->profile) { HIPCHK(c, hipEventRecord(ev.b, stream)); ev.bytes = bytes; c->evts.push_back(ev); }
+  if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
   return 0;
 }
 
@@ -1253,6 +1461,21 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
     if (non_n) HIPCHK(c, hipMemcpyAsync(nonn_dev + s0, non_n + done, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // h_stage is reused by the next round
   }
+  if (!c->fullscan && n_ref > 0) {   // planes derived for this query set (column-compressed scan): whole tiles touched by the append
+    const bool is_db = (tiles == c->d_db);
+    uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
+    int *tote = is_db ? c->d_db_tote : c->d_batch_tote;
+    const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
+    const int nblk = (int)(t1 - t0 + 1);
+    if (c->acgt) {
+      hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote);
+      if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
+    } else {
+      hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote);
+      if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
+    }
+    HIPCHK(c, hipGetLastError());
+  }
   int bad = 0;
   HIPCHK(c, hipMemcpy(&bad, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (bad) {
@@ -1277,7 +1500,8 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+  void *dev[] = {c->d_cls, c->d_qpl, c->d_qc, c->d_flags, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+                 c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -1311,7 +1535,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   const char *env_qt = getenv("UVAIA_GPU_QT");
   if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
   const char *env_scan = getenv("UVAIA_GPU_SCAN");
-  if (env_scan) c->scan_variant = (strcmp(env_scan, "lds") == 0) ? 1 : 0;
+  if (env_scan) c->scan_variant = (strcmp(env_scan, "lds") == 0) ? 1 : (strcmp(env_scan, "sgpr") == 0) ? 0 : 2;
   const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
   c->fullscan = env_full && atoi(env_full) != 0;
   c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
@@ -1379,6 +1603,50 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       }
       OPENCHK(hipMalloc(&c->d_qv, qvh.size() * 4)); OPENCHK(hipMemcpy(c->d_qv, qvh.data(), qvh.size() * 4, hipMemcpyHostToDevice));
     }
+    {  // column classes and compressed/dirty query planes for scan3_kernel
+      const int Wp = c->W4 * 4;
+      auto QL = [&](int i, int w, int pl) -> uint32_t {          // (lo, hi, isACGT, valid-or-isACGT) of query i, word w
+        if (c->acgt) { const uint32_t *s4 = qp.data() + (size_t)i * row_words + (size_t)w * 4; return pl == 3 ? s4[2] : s4[pl]; }
+        const uint32_t *s6 = qp.data() + (size_t)i * row_words + (size_t)w * 6; const uint32_t one = s6[5];
+        return pl == 0 ? ((s6[1] | s6[3]) & one) : pl == 1 ? ((s6[2] | s6[3]) & one) : pl == 2 ? one : s6[4];
+      };
+      std::vector<uint32_t> cls((size_t)Wp * 4, 0u);
+      for (int w = 0; w < Wp; w++) {
+        uint32_t cL = 0, cH = 0, seen = 0, poly = 0;
+        for (int i = 0; i < c->nq; i++) {
+          const uint32_t qL = QL(i, w, 0), qH = QL(i, w, 1), qI = QL(i, w, 2);
+          poly |= seen & qI & ((qL ^ cL) | (qH ^ cH));
+          const uint32_t fresh = qI & ~seen;
+          cL |= qL & fresh; cH |= qH & fresh; seen |= qI;
+        }
+        cls[(size_t)w * 4 + 0] = cL & ~poly; cls[(size_t)w * 4 + 1] = cH & ~poly; cls[(size_t)w * 4 + 2] = seen & ~poly; cls[(size_t)w * 4 + 3] = poly;
+        c->NP += __builtin_popcount(poly);
+      }
+      c->NP4 = ((c->NP + 31) / 32 + 3) / 4;
+      const size_t prow = (size_t)std::max(c->NP4, 1) * 16, crow = (size_t)c->W4 * 8;
+      std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4 * 4, 0u);
+      for (int i = 0; i < c->nq_pad; i++) {
+        int k = 0;                                                   // compressed bit position
+        for (int w = 0; w < Wp; w++) {
+          const bool real = i < c->nq;
+          const uint32_t qL = real ? QL(i, w, 0) : 0u, qH = real ? QL(i, w, 1) : 0u, qI = real ? QL(i, w, 2) : 0u, qV = real ? QL(i, w, 3) : 0u;
+          for (uint32_t m = cls[(size_t)w * 4 + 3]; m; m &= m - 1, k++) {
+            const int b = __builtin_ctz(m);
+            uint32_t *d = qpl.data() + (size_t)i * prow + (size_t)(k >> 5) * 4;
+            d[0] |= ((qL >> b) & 1u) << (k & 31); d[1] |= ((qH >> b) & 1u) << (k & 31); d[2] |= ((qI >> b) & 1u) << (k & 31);
+          }
+          const uint32_t nI = ~qI & cls[(size_t)w * 4 + 2], nV = ~qV;
+          qcv[(size_t)i * crow + (size_t)w * 2 + 0] = nI; qcv[(size_t)i * crow + (size_t)w * 2 + 1] = nV;
+          uint8_t *fb = reinterpret_cast<uint8_t *>(flg.data()) + ((size_t)(i / 16) * c->W4 + (w >> 2)) * 16 + (i % 16);
+          if (nI) *fb |= (uint8_t)(1u << (w & 3));
+          if (nV) *fb |= (uint8_t)(16u << (w & 3));
+        }
+      }
+      OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
+      OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
+      OPENCHK(hipMalloc(&c->d_qc, qcv.size() * 4)); OPENCHK(hipMemcpy(c->d_qc, qcv.data(), qcv.size() * 4, hipMemcpyHostToDevice));
+      OPENCHK(hipMalloc(&c->d_flags, flg.size() * 4)); OPENCHK(hipMemcpy(c->d_flags, flg.data(), flg.size() * 4, hipMemcpyHostToDevice));
+    }
     OPENCHK(hipMalloc(&c->d_amb_q, ambq.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_amb_q, ambq.data(), ambq.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   OPENCHK(hipMalloc(&c->d_qpoly, qpoly.size() * 4)); OPENCHK(hipMemcpy(c->d_qpoly, qpoly.data(), qpoly.size() * 4, hipMemcpyHostToDevice));
@@ -1401,6 +1669,9 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_batch, 0, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
   OPENCHK(hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_batch_ev, (c->pool_pad / 64) * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
+  OPENCHK(hipMalloc(&c->d_batch_poly, (c->pool_pad / 64) * (size_t)std::max(c->NP4, 1) * 3 * 64 * sizeof(uint4)));
+  OPENCHK(hipMalloc(&c->d_batch_tote, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_STRIDE * sizeof(int)));
@@ -1498,12 +1769,16 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   if (!c) return UVAIA_GPU_EINVAL;
   if (cap <= c->db_cap) return 0;
   if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "reserve the database before appending to it");
-  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); hipFree(c->d_db_tot); c->d_db = nullptr; c->d_db_nonn = nullptr; c->d_db_amb = nullptr; c->d_db_tot = nullptr; }
+  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); hipFree(c->d_db_tot); hipFree(c->d_db_ev); hipFree(c->d_db_poly); hipFree(c->d_db_tote);
+                 c->d_db = nullptr; c->d_db_nonn = nullptr; c->d_db_amb = nullptr; c->d_db_tot = nullptr; c->d_db_ev = c->d_db_poly = nullptr; c->d_db_tote = nullptr; }
   const size_t tiles = (cap + 63) / 64 + 1, tile_u4 = (size_t)c->W4 * c->P * 64;
   HIPCHK(c, hipMalloc(&c->d_db, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMemset(c->d_db, 0, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_nonn, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_db_ev, tiles * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_poly, tiles * (size_t)std::max(c->NP4, 1) * 3 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_tote, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_tot, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_tot, 0, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_amb, tiles * 64 * AMB_STRIDE * sizeof(int)));

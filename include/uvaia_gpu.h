@@ -117,8 +117,9 @@ int uvaia_gpu_sync (uvaia_gpu_ctx *ctx);
 size_t uvaia_gpu_state_bytes (const uvaia_gpu_ctx *ctx);
 int uvaia_gpu_state_export (uvaia_gpu_ctx *ctx, void *dst);          /* device or host pointer; returns when dst is complete */
 int uvaia_gpu_state_import (uvaia_gpu_ctx *ctx, const void *src);    /* src may be reused once this returns */
-int uvaia_gpu_slice_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, int buf);
+int uvaia_gpu_slice_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, int buf);      /* buf in [0, uvaia_gpu_slice_buffers()) */
 int uvaia_gpu_slice_replay (uvaia_gpu_ctx *ctx, int buf, int64_t ordinal0, int stripe_start);
+int uvaia_gpu_slice_buffers (void);     /* number of counter buffers: a scan may be issued that many slices ahead of its replay */
 /* The per-query machines are independent, so the state can travel in several blobs, one per contiguous group of queries
  * [q0,q1): while one rank replays group j of a slice the next rank already replays group j-1 of its own slice.
  * take_snapshot: only on the rank that opens a stripe, once it holds the state of ALL queries (the snapshot is a maximum
@@ -146,6 +147,8 @@ int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, d
 int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int reset);
 /* tuning knob: queries held per pass of the scan kernel (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
+/* bytes the pair scan reads per reference (the default scan reads planes derived from the packed record for this query set) */
+size_t uvaia_gpu_scan_bytes_per_ref (const uvaia_gpu_ctx *ctx);
 /* bytes per packed reference in HBM */
 size_t uvaia_gpu_packed_bytes_per_ref (const uvaia_gpu_ctx *ctx);
 

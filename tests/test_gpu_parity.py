@@ -316,3 +316,34 @@ def test_host_non_n_does_not_leak_into_counts(synth):
         assert base[iq].keys() == alt[iq].keys() and len(base[iq]) == len(refs)
         for o in base[iq]:
             assert base[iq][o][:5] == alt[iq][o][:5] and alt[iq][o][5] == 7
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_benchmark_shaped_data_push_and_resident(acgt, monkeypatch):
+    """Generator data at full genome length with k = 100: dozens of tiles per query, tolerances that rise and fall, and a
+    resident search cut into sub-slices (scan several counter buffers ahead of the replay).  Both paths must equal the oracle."""
+    from uvaia_amd import hostlib
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, 40)
+    names = _names(40, "q")
+    refs, non_n = gen.generate_bytes(0, 2600)
+    oq = O.Query(qs, names, acgt=acgt)
+    pq = hostlib.PreparedQuery(qs, names, acgt=acgt)
+    gold = O.search(oq, refs, _names(len(refs)), pool=2600, nbest=100, ambig_r=0.5)
+    want = [[(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(oq.ntax)]
+    with pq.open_engine(nbest=100, max_pool=2600) as e:
+        ent = e.push(refs)
+        n, T, sc, od = e.drain()
+        assert capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T
+        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+    monkeypatch.setenv("UVAIA_GPU_SUBSLICE", "448")      # 6 sub-slices, not tile aligned, ring of counter buffers wraps
+    monkeypatch.setenv("UVAIA_GPU_SUBSLICE_MINQ", "1")
+    with pq.open_engine(nbest=100, max_pool=2600) as e:
+        e.db_reserve(len(refs))
+        e.db_append(refs[:1000]); e.db_append(refs[1000:])
+        for _ in range(2):
+            e.reset()
+            ent = e.search_resident(2600)
+            n, T, sc, od = e.drain()
+            assert capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T
+            assert list(np.nonzero(ent)[0]) == list(gold.saved)

@@ -50,8 +50,11 @@ namespace {
 
 constexpr int HEAP_ENTRY = 8;          // 6 scores + 64-bit ordinal (lo, hi)
 constexpr int AMB_CAP = 11;            // alignment words with a partially ambiguous site remembered per sequence
-constexpr int AMB_STRIDE = AMB_CAP + 1;  // ints per sequence: count (uncapped) + word indices
+constexpr int AMB_STRIDE = AMB_CAP + 1;  // ints per QUERY: count (uncapped) + word indices
+constexpr int AMB_ROW = 64;            // ints per REFERENCE side row (256 B, one coalesced wave load):
+                                       //   [0] count (uncapped)  [1..11] word indices  [12 + 4k + p] plane p of the k-th listed word
 constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
+constexpr int NBUF = 4;                // counter buffers: the scan may run this many slices ahead of the gate/replay
 
 thread_local std::string g_open_error;
 
@@ -63,11 +66,14 @@ struct uvaia_gpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
-  hipEvent_t scan_done[2] = {nullptr, nullptr}, replay_done[2] = {nullptr, nullptr};
-  bool replay_recorded[2] = {false, false}, slice_scanned[2] = {false, false}, slice_cons_done[2] = {false, false};
-  int2 *d_cnt2b = nullptr;                // second counter buffer (ring mode, allocated on first use)
-  int slice_tiles[2] = {0, 0}, slice_rb[2] = {0, 0}, slice_re[2] = {0, 0};
-  long long slice_tf[2] = {0, 0};
+  hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
+  bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
+  int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
+  int *d_tmin[NBUF] = {};                 // per (query, tile of 64 references): smallest mismatch count, one per counter buffer
+  int *d_mp[NBUF] = {};                   // --acgt: mismatches on the polymorphic columns per pair (dist_unique), one per counter buffer
+  int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
+  long long slice_tf[NBUF] = {};
+  size_t subslice = 32768;                // resident search: pools are cut into slices of this size (exact: see search_resident)
   int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16, n_idx_c = 0;
   size_t trim = 0;
   size_t max_pool = 0, pool_pad = 0;
@@ -82,7 +88,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_cls = nullptr;     // [W4*4][4]  cL, cH, constMask, polyMask
   uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][4][4]   compressed polymorphic columns of the queries (L, H, I, -)
   uint32_t *d_qc = nullptr;      // [nq_pad][W4][4][2]    ~qI & constMask, ~qV (default) / ~qI (--acgt)
-  uint32_t *d_flags = nullptr;   // [nq_pad/16][W4][16 bytes]
+  uint32_t *d_flags = nullptr;   // [nq_pad/16][W4]  bit q: query q of the tile is dirty on constant columns, bit 16+q: on validity
   int NP = 0, NP4 = 0;
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
@@ -159,8 +165,9 @@ __constant__ uint8_t c_code[256];
 // One block per tile of 64 database slots; wave v handles word groups w4 = v, v+4, ...  Slots outside
 // [slot0, slot0+n_ref) are left untouched (the database is zero-initialised), so appends need not be tile-aligned.
 // non_n_out (nullable): valid-site count over the FULL length (src/fastaseq.c:642-648).
-// amb_out (nullable): per slot AMB_STRIDE ints = number of alignment words holding a partially ambiguous (valid,
-// non-ACGT) site, then up to AMB_CAP of their indices; a count above AMB_CAP means "list incomplete, rescan densely".
+// amb_out (nullable): per slot a side row of AMB_ROW ints = number of alignment words holding a partially ambiguous (valid,
+// non-ACGT) site, up to AMB_CAP of their indices and the four plane words of each; a count above AMB_CAP means "list
+// incomplete, rescan densely".
 template <int P>
 __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restrict__ chars, size_t pitch, int nchar,
                                                          long long slot0, int n_ref, int W4, uint4 *__restrict__ tiles,
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
   __shared__ int partial_acgt[4][64];
   __shared__ int amb_n[64];
   __shared__ int amb_w[64][AMB_CAP];
+  __shared__ uint32_t amb_p[64][AMB_CAP][4];
   lut[threadIdx.x] = c_code[threadIdx.x];
   if (threadIdx.x < 64) amb_n[threadIdx.x] = 0;
   __syncthreads();
@@ -217,7 +225,10 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
           }
         }
         pl[0][j] = a0; pl[1][j] = a1; pl[2][j] = a2; pl[3][j] = a3;
-        if (partial_code) { const int pos = atomicAdd(&amb_n[lane], 1); if (pos < AMB_CAP) amb_w[lane][pos] = w4 * 4 + j; }
+        if (partial_code) {
+          const int pos = atomicAdd(&amb_n[lane], 1);
+          if (pos < AMB_CAP) { amb_w[lane][pos] = w4 * 4 + j; amb_p[lane][pos][0] = a0; amb_p[lane][pos][1] = a1; amb_p[lane][pos][2] = a2; amb_p[lane][pos][3] = a3; }
+        }
       }
       uint4 *dst = tiles + ((size_t)(tile * W4 + w4) * P) * 64 + lane;
 #pragma unroll
@@ -231,9 +242,13 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
   if (wv == 0 && active && tot_out) tot_out[slot] = (P == 4) ? (partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane])
                                                            : (partial_acgt[0][lane] + partial_acgt[1][lane] + partial_acgt[2][lane] + partial_acgt[3][lane]);
   if (wv == 0 && active && amb_out) {
-    int *a = amb_out + (size_t)slot * AMB_STRIDE;
+    int *a = amb_out + (size_t)slot * AMB_ROW;
     a[0] = amb_n[lane];
-    for (int k = 0; k < AMB_CAP; k++) a[1 + k] = (k < amb_n[lane]) ? amb_w[lane][k] : 0;
+    for (int k = 0; k < AMB_CAP; k++) {
+      const bool have = k < amb_n[lane];
+      a[1 + k] = have ? amb_w[lane][k] : 0;
+      for (int pp = 0; pp < 4; pp++) a[12 + 4 * k + pp] = have ? (int)amb_p[lane][k][pp] : 0;
+    }
   }
   if (bad) atomicOr(errflag, 1);
 }
@@ -589,13 +604,14 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 // scan over the derived planes: acc0 = dense count on the compressed polymorphic words, acc1/acc2 = what the query's
 // non-ACGT / invalid sites take away on the constant columns / from the valid count (dirty word groups only).
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
-// flags[qtile][w4][q] : bit j = query word 4*w4+j is not all-ACGT on a constant column, bit 4+j = not all valid (ACGT)
-// qc[q][w4][j][2]     : ~qI & constMask, ~qV (default) / ~qI (--acgt)            qpl[q][p4][j][4]: compressed L, H, I
+// flags[qtile][w4]    : bit q = query q of the tile is not all-ACGT on a constant column in this word group, bit 16+q = not all valid
+// qc[q][w4][2][4]     : ~qI & constMask (4 words), ~qV (default) / ~qI (--acgt) (4 words)   qpl[q][p4][j][4]: compressed L, H, I
 template <int QT, bool ACGT>
 __global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
                                                      int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ qc,
                                                      const uint32_t *__restrict__ flags, const int *__restrict__ tot_e, const int *__restrict__ tot_v,
-                                                     int2 *__restrict__ out, int ppad, int n_qtiles)
+                                                     int2 *__restrict__ out, int ppad, int n_qtiles, int *__restrict__ tmin, int r_lo, int r_hi,
+                                                     int *__restrict__ mp_out)
 {
   static_assert(QT == 16, "flag words are laid out for tiles of 16 queries");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -633,38 +649,49 @@ __global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev
       }
     }
   }
-  // ---- constant columns and validity: only where a query is dirty
+  // ---- constant columns and validity: only where a query is dirty.  One flag dword per word group: bit q = query q of the
+  // tile is not all-ACGT on a constant column here, bit 16+q = it has an invalid site here; every test is one scalar bit test.
   {
     const uint4 *t = ev + (size_t)(tile_first + trel) * W4 * 2 * 64 + lane;
-    const uint32_t *fl = flags + (size_t)qtile * W4 * 4;                 // 16 flag bytes = 4 dwords per word group
+    const uint32_t *fl = flags + (size_t)qtile * W4;
     const size_t qstride = (size_t)W4 * 8;
     const uint32_t *qb = qc + (size_t)q0 * qstride;
     for (int w4 = 0; w4 < W4; w4++) {
-      const uint32_t f0 = fl[w4 * 4 + 0], f1 = fl[w4 * 4 + 1], f2 = fl[w4 * 4 + 2], f3 = fl[w4 * 4 + 3];
-      if ((f0 | f1 | f2 | f3) == 0u) continue;                           // every query of the tile is clean here
-      const uint4 pE = t[(size_t)(w4 * 2 + 0) * 64], pV = t[(size_t)(w4 * 2 + 1) * 64];
+      const uint32_t f = fl[w4];
+      if (f == 0u) continue;                                             // every query of the tile is clean here
+      const uint4 pE = (f & 0xFFFFu) ? t[(size_t)(w4 * 2 + 0) * 64] : make_uint4(0, 0, 0, 0);
+      const uint4 pV = (f >> 16) ? t[(size_t)(w4 * 2 + 1) * 64] : make_uint4(0, 0, 0, 0);
       const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
 #pragma unroll
       for (int q = 0; q < QT; q++) {
-        const uint32_t fw = (q < 4) ? f0 : (q < 8) ? f1 : (q < 12) ? f2 : f3;
-        const uint32_t f = (fw >> ((q & 3) * 8)) & 0xFFu;
-        if (f == 0u) continue;                                           // wave-uniform: the flags live in scalar registers
-        const uint32_t *s = qb + (size_t)q * qstride + (size_t)w4 * 8;
-        if (f & 0x0Fu) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[q][1] = bcnt_acc(rE[j] & s[j * 2 + 0], acc[q][1]);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(qb + (size_t)q * qstride + (size_t)w4 * 8);   // [0] ~qI & constMask, [1] ~qV
+        if (f & (1u << q)) {
+          const uint4 sI = s4[0];                                        // one s_load_dwordx4
+          acc[q][1] = bcnt_acc(rE[0] & sI.x, acc[q][1]); acc[q][1] = bcnt_acc(rE[1] & sI.y, acc[q][1]);
+          acc[q][1] = bcnt_acc(rE[2] & sI.z, acc[q][1]); acc[q][1] = bcnt_acc(rE[3] & sI.w, acc[q][1]);
         }
-        if (f & 0xF0u) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[q][2] = bcnt_acc(rV[j] & s[j * 2 + 1], acc[q][2]);
+        if (f & (0x10000u << q)) {
+          const uint4 sV = s4[1];
+          acc[q][2] = bcnt_acc(rV[0] & sV.x, acc[q][2]); acc[q][2] = bcnt_acc(rV[1] & sV.y, acc[q][2]);
+          acc[q][2] = bcnt_acc(rV[2] & sV.z, acc[q][2]); acc[q][2] = bcnt_acc(rV[3] & sV.w, acc[q][2]);
         }
       }
     }
   }
   const size_t r = (size_t)trel * 64 + lane;
   const int te = tot_e[r], tv = tot_v[r];
+  const bool in_batch = ((int)r >= r_lo && (int)r < r_hi);
 #pragma unroll
-  for (int q = 0; q < QT; q++) out[(size_t)(q0 + q) * ppad + r] = make_int2(acc[q][0] + te - acc[q][1], tv - acc[q][2]);
+  for (int q = 0; q < QT; q++) {
+    const int c0 = acc[q][0] + te - acc[q][1], c1 = tv - acc[q][2];
+    out[(size_t)(q0 + q) * ppad + r] = make_int2(c0, c1);
+    if (ACGT) mp_out[(size_t)(q0 + q) * ppad + r] = acc[q][0];      // mismatches on the polymorphic columns = dist_unique
+    // smallest mismatch count of the tile: lets the replay skip tiles that cannot pass the gate (src/nearest.c:488) at all
+    int m = in_batch ? (ACGT ? c0 : c1 - c0) : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+    if (lane == 0) tmin[(size_t)(q0 + q) * (ppad >> 6) + trel] = m;
+  }
 }
 
 // LDS-broadcast variant of the two-counter scan.  Measured on MI355X (profiles/r01_valu_rate_microbench.txt): a VALU
@@ -1054,23 +1081,57 @@ static __device__ __forceinline__ void iupac_word_extra(const uint32_t *__restri
 // Default mode: text_matches - ACGT_matches and partial_matches - text_matches of one pair.  Both differences live on
 // sites where the query or the reference carries a partially ambiguous code, so only the alignment words listed for
 // either sequence are visited (all words if a list overflowed).  Whole wave cooperates; result in every lane.
-static __device__ int2 wave_iupac_extra(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *__restrict__ qrow6,
-                                        const int *__restrict__ amb_r, const int *__restrict__ amb_q, int lane, bool &dense)
+// one word's contribution given both sets of four planes
+static __device__ __forceinline__ void iupac_planes_extra(uint32_t rA, uint32_t rC, uint32_t rG, uint32_t rT, uint32_t qA, uint32_t qC, uint32_t qG, uint32_t qT_,
+                                                          uint32_t qa, int &d1, int &d2)
+{
+  const uint32_t rv = rA | rC | rG | rT;
+  const uint32_t nd = ~((rA ^ qA) | (rC ^ qC) | (rG ^ qG) | (rT ^ qT_));
+  const uint32_t e = nd & rv, a0 = nd & qa, x = (rA & qA) | (rC & qC) | (rG & qG) | (rT & qT_);
+  d1 += __popc(e & ~a0);
+  d2 += __popc(x & ~e);
+}
+
+// Single round trip: the reference's side row (count, listed words and their planes) is one coalesced 256-B load, the
+// reference planes at the query's listed words are requested at the same time (they do not depend on the row), and the
+// query's planes come from `qw` (LDS copy of its row when it fits, else global memory).
+static __device__ int2 wave_iupac_extra(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *qw,
+                                        const int *__restrict__ ref_row, int aqv /*lane l < AMB_STRIDE holds the query's list*/, int lane, bool &dense)
 {
   const uint32_t *dbw = reinterpret_cast<const uint32_t *>(db);
-  const int nr = amb_r[0], nq = amb_q[0];
+  const int nq = __shfl(aqv, 0);
+  const int row = ref_row[lane];
+  const int wq = __shfl(aqv, 1 + ((lane < nq && lane < AMB_CAP) ? lane : 0));
+  uint32_t gA = 0, gC = 0, gG = 0, gT = 0;
+  if (lane < nq && nq <= AMB_CAP) {
+    const size_t base = (((size_t)tile_abs * W4 + (wq >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (wq & 3);
+    gA = dbw[base]; gC = dbw[base + 256]; gG = dbw[base + 512]; gT = dbw[base + 768];
+  }
+  const int nr = __shfl(row, 0);
   int d1 = 0, d2 = 0;
   dense = (nr > AMB_CAP || nq > AMB_CAP);
   if (!dense) {
+    // lanes 0..nq-1: the query's words;  lanes nq..nq+nr-1: the reference's words the query does not list itself
+    const int kr = (lane >= nq && lane < nq + nr) ? lane - nq : 0;
+    const int wr = __shfl(row, 1 + kr);
+    const uint32_t sA = (uint32_t)__shfl(row, 12 + 4 * kr + 0), sC = (uint32_t)__shfl(row, 12 + 4 * kr + 1),
+                   sG = (uint32_t)__shfl(row, 12 + 4 * kr + 2), sT = (uint32_t)__shfl(row, 12 + 4 * kr + 3);
+    bool dup = false;
+    for (int k = 0; k < nq; k++) dup |= (__shfl(aqv, 1 + k) == wr);
     int w = -1;
-    if (lane < nq) w = amb_q[1 + lane];
-    else if (lane < nq + nr) {
-      w = amb_r[1 + lane - nq];
-      for (int k = 0; k < nq; k++) if (amb_q[1 + k] == w) w = -1;     // already covered by the query's list
+    uint32_t rA = 0, rC = 0, rG = 0, rT = 0;
+    if (lane < nq) { w = wq; rA = gA; rC = gC; rG = gG; rT = gT; }
+    else if (lane < nq + nr && !dup) { w = wr; rA = sA; rC = sC; rG = sG; rT = sT; }
+    if (w >= 0) {
+      const uint32_t *sq = qw + (size_t)w * 6;
+      iupac_planes_extra(rA, rC, rG, rT, sq[0], sq[1], sq[2], sq[3], sq[5], d1, d2);
     }
-    if (w >= 0) iupac_word_extra(dbw, tile_abs, lane_r, W4, qrow6, w, d1, d2);
   } else {
-    for (int w = lane; w < W4 * 4; w += 64) iupac_word_extra(dbw, tile_abs, lane_r, W4, qrow6, w, d1, d2);
+    for (int w = lane; w < W4 * 4; w += 64) {
+      const size_t base = (((size_t)tile_abs * W4 + (w >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (w & 3);
+      const uint32_t *sq = qw + (size_t)w * 6;
+      iupac_planes_extra(dbw[base], dbw[base + 256], dbw[base + 512], dbw[base + 768], sq[0], sq[1], sq[2], sq[3], sq[5], d1, d2);
+    }
   }
   return make_int2(wave_sum(d1), wave_sum(d2));
 }
@@ -1105,10 +1166,10 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
                                                       const int *__restrict__ snap_ptr, uint8_t *__restrict__ entered, int k,
                                                       const uint4 *__restrict__ db, long long tile_first, int W4,
                                                       const uint32_t *__restrict__ qfull, const int *__restrict__ amb_q,
-                                                      unsigned long long *__restrict__ stats, int q_first)
+                                                      unsigned long long *__restrict__ stats, int q_first, const int *__restrict__ tmin,
+                                                      const int *__restrict__ mpbuf, int lq_words)
 {
   extern __shared__ int h[];
-  constexpr int U = 4;
   __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
   const int q = blockIdx.x + q_first, lane = threadIdx.x;
   int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
@@ -1124,106 +1185,147 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   }
   const int2 *crow = cnt + (size_t)q * ppad;
   const uint32_t *qrow = qfull + (size_t)q * W4 * 4 * (ACGT ? 4 : 6);
-  const int *aq = amb_q + (size_t)q * AMB_STRIDE;
+  // default mode: keep the query's full planes in LDS (behind the heap) when they fit; the on-demand counters then need a
+  // single global round trip per pair
+  const uint32_t *qw = qrow;
+  if (!ACGT && lq_words > 0) {
+    uint32_t *lq = reinterpret_cast<uint32_t *>(h + (k + 1) * HEAP_ENTRY);
+    for (int i = lane; i < lq_words; i += 64) lq[i] = qrow[i];
+    qw = lq;
+  }
+  const int aqv = (lane < AMB_STRIDE) ? amb_q[(size_t)q * AMB_STRIDE + lane] : 0;      // the query's ambiguity-word list, one int per lane
+  __syncthreads();
   bool dirty = false;
   unsigned n_admit = 0, n_demand = 0, n_dense = 0;
   // software pipeline: the counters of round i+1 are requested before round i is processed (the kernel is latency bound:
   // one wave per query, a few hundred dependent rounds)
-  int2 pc[U]; int4 pa[U], prc[U]; int pnn[U];
-  auto fetch = [&](int base) {
+  // Traversal.  Tiles (64 references) whose smallest mismatch count is not below the current tolerance cannot produce an
+  // admission, and the tolerance only changes through admissions; so the wave walks the tile minima (64 tiles per load) and
+  // fetches pair counters only for tiles that can pass the gate now, four tiles in flight.  After an admission that changed
+  // the tolerance the set of needed tiles is derived again (a tile skipped earlier may qualify once the tolerance rises).
+  // Exact for any sequence of tolerances.  With consensus counters in play (CONS) every tile is visited.
+  const bool use_tmin = !CONS && tmin != nullptr;
+  const int *tmrow = use_tmin ? tmin + (size_t)q * (ppad >> 6) : nullptr;
+  const int n_slice_tiles = (r_end + 63) >> 6;
+  constexpr int D = 4;
+  for (int tb = 0; tb < n_slice_tiles; tb += 64) {
+    int tm = 0x7fffffff;
+    if (tb + lane < n_slice_tiles) tm = use_tmin ? tmrow[tb + lane] : -1;
+    unsigned long long P = __ballot(tm < T);
+    while (P) {
+      int tsel[D]; int2 c[D]; int4 a[D], rc[D]; int nn[D], m[D], K0[D], K1[D], K2[D], K3[D]; bool valid[D];
+      {
+        unsigned long long rest = P;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int r = base + u * 64 + lane;
-      pc[u] = make_int2(0, 0); pa[u] = prc[u] = make_int4(0, 0, 0, 0); pnn[u] = 0;
-      if (r < r_end) {
-        pc[u] = crow[r];
-        if (CONS) { pa[u] = rt[r]; prc[u] = tr[r]; }
-        if (CONS || ACGT) pnn[u] = nonn[r];
+        for (int i = 0; i < D; i++) { tsel[i] = rest ? (__ffsll((long long)rest) - 1) : -1; rest &= rest - 1; }
       }
-    }
-  };
-  fetch(r_begin);
-  for (int base = r_begin; base < r_end; base += 64 * U) {
-    int2 c[U]; int4 a[U], rc[U]; int nn[U], m[U], K0[U], K1[U], K2[U], K3[U]; bool valid[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) { c[u] = pc[u]; a[u] = pa[u]; rc[u] = prc[u]; nn[u] = pnn[u]; valid[u] = (base + u * 64 + lane) < r_end; }
-    if (base + 64 * U < r_end) fetch(base + 64 * U);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int mc_true = ACGT ? a[u].x : (a[u].w - a[u].x);
-      if (mc_true < snap) rc[u] = a[u];                   // cq->res was not cut short (src/nearest.c:431-432)
-      if (ACGT) {       // keys 0..3 are known from the two counters: matches, valid, unique matches, valid ref sites
-        K1[u] = c[u].y - a[u].y + rc[u].y;
-        K0[u] = K1[u] - (c[u].x - a[u].x + rc[u].x);
-        K2[u] = K0[u] - (rc[u].y - rc[u].x);
-        K3[u] = nn[u];
-        m[u] = K1[u] - K0[u];
-      } else {          // only key 0 (ACGT matches) and the pair's valid count are known
-        K0[u] = c[u].x - a[u].x + rc[u].x;
-        K3[u] = c[u].y - a[u].w + rc[u].w;
-        K1[u] = K2[u] = 0;
-        m[u] = K3[u] - K0[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      auto may_enter = [&]() -> bool {
-        if (!valid[u] || m[u] >= T) return false;
-        if (!full) return true;
-        if (ACGT) {
-          if (K0[u] != W[0]) return K0[u] > W[0];
-          if (K1[u] != W[1]) return K1[u] > W[1];
-          if (K2[u] != W[2]) return K2[u] > W[2];
-          return K3[u] >= W[3];
-        }
-        return K0[u] >= W[0];
-      };
-      unsigned long long mask = __ballot(may_enter());
-      while (mask) {
-        const int i = __ffsll((long long)mask) - 1;
-        const int rl = base + u * 64 + i;                                 // index relative to the first tile of the batch
-        const int cx = __shfl(c[u].x, i), cy = __shfl(c[u].y, i);
-        const int4 ai = make_int4(__shfl(a[u].x, i), __shfl(a[u].y, i), __shfl(a[u].z, i), __shfl(a[u].w, i));
-        const int4 ri = make_int4(__shfl(rc[u].x, i), __shfl(rc[u].y, i), __shfl(rc[u].z, i), __shfl(rc[u].w, i));
-        const int nni = (CONS || ACGT) ? __shfl(nn[u], i) : nonn[rl];
-        const size_t tile_abs = (size_t)tile_first + (size_t)(rl >> 6);
-        int Si[6], mi;
-        n_demand++;
-        if (ACGT) {
-          const int mp = wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
-          assemble_scores<true>(make_int4(cx, cy, mp, 0), ai, ri, nni, Si, mi);
-        } else {
-          bool dense;
-          const int2 d = wave_iupac_extra(db, tile_abs, rl & 63, W4, qrow, amb + (size_t)rl * AMB_STRIDE, aq, lane, dense);
-          n_dense += dense;
-          assemble_scores<false>(make_int4(cx, cx + d.x, cx + d.x + d.y, cy), ai, ri, nni, Si, mi);
-        }
-        const bool accept = (mi < T) && (!full || lex_better(Si, W));     // src/nearest.c:488-496 + heap_insert :93-117
-        if (!accept) { mask &= mask - 1; continue; }
-        {
-          const long long ord = ord_base + (rl - r_begin);
-          const int slot = full ? 1 : n + 1;
-          if (lane < HEAP_ENTRY) {
-            int v = (int)(unsigned)(ord & 0xffffffffll);
-            if (lane == 7) v = (int)(ord >> 32);
-#pragma unroll
-            for (int s = 0; s < 6; s++) if (lane == s) v = Si[s];
-            h[slot * HEAP_ENTRY + lane] = v;
+      for (int i = 0; i < D; i++) {                                    // request the counters of up to D needed tiles
+        c[i] = make_int2(0, 0); a[i] = rc[i] = make_int4(0, 0, 0, 0); nn[i] = 0; valid[i] = false;
+        if (tsel[i] >= 0) {
+          const int r = (tb + tsel[i]) * 64 + lane;
+          valid[i] = (r >= r_begin && r < r_end);
+          if (valid[i]) {
+            c[i] = crow[r];
+            if (CONS) { a[i] = rt[r]; rc[i] = tr[r]; }
+            if (CONS || ACGT) nn[i] = nonn[r];
           }
-          if (lane == 0) entered[rl] = 1;
-          __syncthreads();
-          if (full) wave_sift_down(h, n, 1, lane); else wave_sift_up(h, n + 1, lane);
         }
-        if (!full) n++;
-        dirty = true; n_admit++;
-        __syncthreads();
-        full = (n == k);
-        if (full) {
+      }
+      bool regroup = false;
 #pragma unroll
-          for (int s = 0; s < 6; s++) W[s] = h[HEAP_ENTRY + s];
-          T = entry_mismatches<ACGT>(W) + 1;                               // src/nearest.c:506-508 / :474-475
+      for (int u = 0; u < D; u++) {
+        if (tsel[u] < 0 || regroup) continue;
+        {
+          const int mc_true = ACGT ? a[u].x : (a[u].w - a[u].x);
+          if (mc_true < snap) rc[u] = a[u];                 // cq->res was not cut short (src/nearest.c:431-432)
+          if (ACGT) {     // keys 0..3 are known from the two counters: matches, valid, unique matches, valid ref sites
+            K1[u] = c[u].y - a[u].y + rc[u].y;
+            K0[u] = K1[u] - (c[u].x - a[u].x + rc[u].x);
+            K2[u] = K0[u] - (rc[u].y - rc[u].x);
+            K3[u] = nn[u];
+            m[u] = K1[u] - K0[u];
+          } else {        // only key 0 (ACGT matches) and the pair's valid count are known
+            K0[u] = c[u].x - a[u].x + rc[u].x;
+            K3[u] = c[u].y - a[u].w + rc[u].w;
+            K1[u] = K2[u] = 0;
+            m[u] = K3[u] - K0[u];
+          }
         }
-        mask = __ballot(lane > i && may_enter());
+        const int T_used = T;
+        const int base_u = (tb + tsel[u]) * 64;
+        auto may_enter = [&]() -> bool {
+          if (!valid[u] || m[u] >= T) return false;
+          if (!full) return true;
+          if (ACGT) {
+            if (K0[u] != W[0]) return K0[u] > W[0];
+            if (K1[u] != W[1]) return K1[u] > W[1];
+            if (K2[u] != W[2]) return K2[u] > W[2];
+            return K3[u] >= W[3];
+          }
+          return K0[u] >= W[0];
+        };
+        unsigned long long mask = __ballot(may_enter());
+        while (mask) {
+          const int i = __ffsll((long long)mask) - 1;
+          const int rl = base_u + i;                                      // index relative to the first tile of the batch
+          const int cx = __shfl(c[u].x, i), cy = __shfl(c[u].y, i);
+          const int4 ai = make_int4(__shfl(a[u].x, i), __shfl(a[u].y, i), __shfl(a[u].z, i), __shfl(a[u].w, i));
+          const int4 ri = make_int4(__shfl(rc[u].x, i), __shfl(rc[u].y, i), __shfl(rc[u].z, i), __shfl(rc[u].w, i));
+          const int nni = (CONS || ACGT) ? __shfl(nn[u], i) : nonn[rl];
+          const size_t tile_abs = (size_t)tile_first + (size_t)(rl >> 6);
+          int Si[6], mi;
+          n_demand++;
+          if (ACGT) {
+            // with the column-compressed scan the dense count on the polymorphic columns IS score[5] (src/nearest.c:469)
+            const int mp = mpbuf ? mpbuf[(size_t)q * ppad + rl] : wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
+            assemble_scores<true>(make_int4(cx, cy, mp, 0), ai, ri, nni, Si, mi);
+          } else {
+            bool dense;
+            const int2 d = wave_iupac_extra(db, tile_abs, rl & 63, W4, qw, amb + (size_t)rl * AMB_ROW, aqv, lane, dense);
+            n_dense += dense;
+            assemble_scores<false>(make_int4(cx, cx + d.x, cx + d.x + d.y, cy), ai, ri, nni, Si, mi);
+          }
+          const bool accept = (mi < T) && (!full || lex_better(Si, W));   // src/nearest.c:488-496 + heap_insert :93-117
+          if (!accept) { mask &= mask - 1; continue; }
+          {
+            const long long ord = ord_base + (rl - r_begin);
+            const int slot = full ? 1 : n + 1;
+            if (lane < HEAP_ENTRY) {
+              int v = (int)(unsigned)(ord & 0xffffffffll);
+              if (lane == 7) v = (int)(ord >> 32);
+#pragma unroll
+              for (int sidx = 0; sidx < 6; sidx++) if (lane == sidx) v = Si[sidx];
+              h[slot * HEAP_ENTRY + lane] = v;
+            }
+            if (lane == 0) entered[rl] = 1;
+            __syncthreads();
+            if (full) wave_sift_down(h, n, 1, lane); else wave_sift_up(h, n + 1, lane);
+          }
+          if (!full) n++;
+          dirty = true; n_admit++;
+          __syncthreads();
+          full = (n == k);
+          if (full) {
+#pragma unroll
+            for (int sidx = 0; sidx < 6; sidx++) W[sidx] = h[HEAP_ENTRY + sidx];
+            T = entry_mismatches<ACGT>(W) + 1;                             // src/nearest.c:506-508 / :474-475
+          }
+          mask = __ballot(lane > i && may_enter());
+        }
+        P &= ~(1ull << tsel[u]);                                          // this tile is done
+        if (T != T_used) {
+          // Needed tiles under the new tolerance, after this one.  A lower tolerance only removes tiles: the ones already in
+          // flight are processed anyway (their ballots come out empty).  A higher tolerance can add a tile that lies BEFORE
+          // the next tile in flight; only then must the group be formed again to keep the stream order.
+          P = __ballot(tm < T) & ~((2ull << tsel[u]) - 1ull);
+          unsigned long long inflight = 0ull; int last = -1;
+#pragma unroll
+          for (int v = 0; v < D; v++) if (v > u && tsel[v] >= 0) { inflight |= (1ull << tsel[v]); last = tsel[v]; }
+          // a needed tile that is not in flight but precedes the last tile in flight would be visited out of order
+          if (T > T_used && last >= 0 && (P & ~inflight & ((1ull << last) - 1ull)) != 0ull) regroup = true;
+          else P |= inflight;                                             // keep the tiles in flight in the pending set
+        }
       }
     }
   }
@@ -1338,7 +1440,8 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
   return 0;
 }
 
-int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream = nullptr)
+int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream,
+                 int *tmin, int r_lo, int r_hi, int *mp)
 {
   if (n_tiles <= 0) return 0;
   if (!stream) stream = c->stream;
@@ -1356,8 +1459,8 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const int nqt3 = (c->nq + 15) / 16;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3);
+    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1418,7 +1521,8 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   }
   HIPCHK(c, hipGetLastError());
   const double bytes = (double)(r_end - r_begin) * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  const int lq_words = (!c->acgt && !c->fullscan && lds + (size_t)c->W4 * 4 * 6 * 4 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;   // query planes cached in LDS
   if (c->fullscan) {
     int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
     rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq, c->d_cnt, ppad, bytes);
@@ -1426,10 +1530,11 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
     else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
   } else {
-    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes);
+    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0]);
     if (rc) return rc;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
-                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0)
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int *)nullptr, \
+                                    c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1476,6 +1581,7 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
     }
     HIPCHK(c, hipGetLastError());
   }
+  HIPCHK(c, hipStreamSynchronize(c->stream));     // scans may start on another stream: the packed and derived planes must be complete
   int bad = 0;
   HIPCHK(c, hipMemcpy(&bad, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (bad) {
@@ -1505,8 +1611,8 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
-  if (c->d_cnt2b) hipFree(c->d_cnt2b);
-  for (int i = 0; i < 2; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
+  for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); }
+  for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
   if (c->scan_stream) hipStreamDestroy(c->scan_stream);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -1549,7 +1655,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     OPENCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     OPENCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
     OPENCHK(hipStreamCreateWithPriority(&c->scan_stream, hipStreamNonBlocking, prio_least));
-    for (int i = 0; i < 2; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
+    for (int i = 0; i < NBUF; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
   }
   uint8_t code_tab[256]; fill_code_table(code_tab);
   OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
@@ -1624,7 +1730,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       }
       c->NP4 = ((c->NP + 31) / 32 + 3) / 4;
       const size_t prow = (size_t)std::max(c->NP4, 1) * 16, crow = (size_t)c->W4 * 8;
-      std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4 * 4, 0u);
+      std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4, 0u);
       for (int i = 0; i < c->nq_pad; i++) {
         int k = 0;                                                   // compressed bit position
         for (int w = 0; w < Wp; w++) {
@@ -1636,10 +1742,10 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
             d[0] |= ((qL >> b) & 1u) << (k & 31); d[1] |= ((qH >> b) & 1u) << (k & 31); d[2] |= ((qI >> b) & 1u) << (k & 31);
           }
           const uint32_t nI = ~qI & cls[(size_t)w * 4 + 2], nV = ~qV;
-          qcv[(size_t)i * crow + (size_t)w * 2 + 0] = nI; qcv[(size_t)i * crow + (size_t)w * 2 + 1] = nV;
-          uint8_t *fb = reinterpret_cast<uint8_t *>(flg.data()) + ((size_t)(i / 16) * c->W4 + (w >> 2)) * 16 + (i % 16);
-          if (nI) *fb |= (uint8_t)(1u << (w & 3));
-          if (nV) *fb |= (uint8_t)(16u << (w & 3));
+          qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + (w & 3)] = nI; qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + 4 + (w & 3)] = nV;
+          uint32_t &fw = flg[(size_t)(i / 16) * c->W4 + (w >> 2)];
+          if (real && nI) fw |= 1u << (i % 16);          // padding queries of the last tile are never read back: keep them "clean"
+          if (real && nV) fw |= 0x10000u << (i % 16);
         }
       }
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
@@ -1674,9 +1780,12 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_batch_tote, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_STRIDE * sizeof(int)));
-  OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_STRIDE * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_ROW * sizeof(int)));
+  OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_ROW * sizeof(int)));
   if (!c->fullscan) OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int)));
+  { const char *env_sub = getenv("UVAIA_GPU_SUBSLICE"); if (env_sub && atol(env_sub) >= 64) c->subslice = (size_t)atol(env_sub); }
+  if (c->acgt && !c->fullscan && c->scan_variant == 2) OPENCHK(hipMalloc(&c->d_mp[0], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMalloc(&c->d_rt, c->pool_pad * sizeof(int4)));
@@ -1720,6 +1829,11 @@ int uvaia_gpu_reset(uvaia_gpu_ctx *c)
 int uvaia_gpu_heap_slots(const uvaia_gpu_ctx *c) { return c ? c->k : 0; }
 int uvaia_gpu_n_query(const uvaia_gpu_ctx *c) { return c ? c->nq : 0; }
 size_t uvaia_gpu_packed_bytes_per_ref(const uvaia_gpu_ctx *c) { return c ? (size_t)c->W4 * 16 * c->P : 0; }
+size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
+{ // what the default scan reads per reference: two derived planes over the whole alignment + three planes of the gathered polymorphic columns
+  if (!c) return 0;
+  return (c->fullscan || c->scan_variant != 2) ? (size_t)c->W4 * 16 * c->P : (size_t)c->W4 * 16 * 2 + (size_t)c->NP4 * 16 * 3;
+}
 
 int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
 {
@@ -1781,8 +1895,8 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   HIPCHK(c, hipMalloc(&c->d_db_tote, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_tot, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_tot, 0, tiles * 64 * sizeof(int)));
-  HIPCHK(c, hipMalloc(&c->d_db_amb, tiles * 64 * AMB_STRIDE * sizeof(int)));
-  HIPCHK(c, hipMemset(c->d_db_amb, 0, tiles * 64 * AMB_STRIDE * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_db_amb, tiles * 64 * AMB_ROW * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_db_amb, 0, tiles * 64 * AMB_ROW * sizeof(int)));
   c->db_cap = tiles * 64 - 64;
   if (c->entered_cap < tiles * 64) {
     hipFree(c->d_entered); c->d_entered = nullptr;
@@ -1825,14 +1939,27 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
   if (!c->db_n) return 0;
   HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
   if (!c->fullscan) {
-    // two streams: while batch i goes through the gate, batch i+1 is already being scanned (the scan needs no state)
-    const size_t nb = (c->db_n + pool - 1) / pool;
-    int rc = uvaia_gpu_slice_scan(c, 0, std::min(pool, c->db_n), 0);
-    if (rc) return rc;
-    for (size_t i = 0; i < nb; i++) {
-      const size_t a = i * pool;
-      if (i + 1 < nb) { rc = uvaia_gpu_slice_scan(c, a + pool, std::min(pool, c->db_n - a - pool), (int)((i + 1) & 1)); if (rc) return rc; }
-      rc = uvaia_gpu_slice_replay(c, (int)(i & 1), ordinal0 + (long long)a, 1);
+    // Two streams and a ring of NBUF counter buffers: the scan needs no state, so it runs up to NBUF-1 slices ahead of the
+    // gate/replay.  Each pool is cut into sub-slices; that is exact because the only thing a pool boundary does is retake the
+    // snapshot of the tolerances (src/nearest.c:290-291), which happens at the first sub-slice of a pool only.
+    struct Sub { size_t first, n; bool pool_start; };
+    std::vector<Sub> subs;
+    // with few queries the replay is negligible and small launches only cost: one slice per pool then
+    const char *env_minq = getenv("UVAIA_GPU_SUBSLICE_MINQ");
+    const size_t sub = (c->nq >= (env_minq ? atoi(env_minq) : 256)) ? c->subslice : pool;
+    for (size_t a = 0; a < c->db_n; a += pool) {
+      const size_t pe = std::min(c->db_n, a + pool);
+      for (size_t x = a; x < pe; x += sub) subs.push_back({x, std::min(sub, pe - x), x == a});
+    }
+    const size_t ns = subs.size();
+    size_t issued = 0;
+    for (size_t i = 0; i < ns; i++) {
+      while (issued < ns && issued < i + NBUF) {          // keep the scan stream fed
+        int rc = uvaia_gpu_slice_scan(c, subs[issued].first, subs[issued].n, (int)(issued % NBUF));
+        if (rc) return rc;
+        issued++;
+      }
+      int rc = uvaia_gpu_slice_replay(c, (int)(i % NBUF), ordinal0 + (long long)subs[i].first, subs[i].pool_start ? 1 : 0);
       if (rc) return rc;
     }
   } else
@@ -1841,7 +1968,7 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
     const long long tf = (long long)(a / 64);
     const int n_tiles = (int)((b + 63) / 64 - a / 64);
     const int rb = (int)(a - (size_t)tf * 64), re = (int)(b - (size_t)tf * 64);
-    int rc = run_batch(c, c->d_db, c->d_db_nonn + tf * 64, c->d_db_amb + tf * 64 * AMB_STRIDE, tf, n_tiles, rb, re, ordinal0 + (long long)a, c->d_entered + tf * 64);
+    int rc = run_batch(c, c->d_db, c->d_db_nonn + tf * 64, c->d_db_amb + tf * 64 * AMB_ROW, tf, n_tiles, rb, re, ordinal0 + (long long)a, c->d_entered + tf * 64);
     if (rc) return rc;
   }
   if (entered) {
@@ -1954,10 +2081,12 @@ int uvaia_gpu_state_import(uvaia_gpu_ctx *c, const void *src) { return c ? uvaia
 // counts of database references [first, first+n) into counter buffer `buf` (0/1), asynchronously on the scan stream
 int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
 {
-  if (!c || buf < 0 || buf > 1) return UVAIA_GPU_EINVAL;
+  if (!c || buf < 0 || buf >= NBUF) return UVAIA_GPU_EINVAL;
   if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "ring mode needs the two-counter scan");
   if (first + n > c->db_n || n > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database or above max_pool", first, n);
-  if (buf == 1 && !c->d_cnt2b) HIPCHK(c, hipMalloc(&c->d_cnt2b, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  if (buf > 0 && !c->d_cntb[buf]) HIPCHK(c, hipMalloc(&c->d_cntb[buf], (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  if (!c->d_tmin[buf]) HIPCHK(c, hipMalloc(&c->d_tmin[buf], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int)));
+  if (c->d_mp[0] && !c->d_mp[buf]) HIPCHK(c, hipMalloc(&c->d_mp[buf], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
   const long long tf = (long long)(first / 64);
   const int n_tiles = n ? (int)((first + n + 63) / 64 - first / 64) : 0;
@@ -1965,7 +2094,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
   c->slice_scanned[buf] = true; c->slice_cons_done[buf] = false;
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cnt2b : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream);
+  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_mp[buf]);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->scan_done[buf], c->scan_stream));
   return 0;
@@ -1976,7 +2105,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
 // src/nearest.c:290-291) is taken from the state of ALL queries now held; otherwise the imported snapshot is used.
 int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int q0, int q1, int take_snapshot)
 {
-  if (!c || buf < 0 || buf > 1) return UVAIA_GPU_EINVAL;
+  if (!c || buf < 0 || buf >= NBUF) return UVAIA_GPU_EINVAL;
   if (!c->slice_scanned[buf]) return fail(c, UVAIA_GPU_ESTATE, "slice_replay without slice_scan");
   if (q0 < 0 || q1 > c->nq || q1 < q0) return fail(c, UVAIA_GPU_EINVAL, "bad query range [%d,%d)", q0, q1);
   const int n_tiles = c->slice_tiles[buf], rb = c->slice_rb[buf], re = c->slice_re[buf];
@@ -1991,11 +2120,13 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
     c->slice_cons_done[buf] = true;
   }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
-  const int2 *cnt = buf ? c->d_cnt2b : c->d_cnt2;
-  const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_STRIDE;
+  const int lq_words = (!c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
+  const int2 *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
+  const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0)
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int *)nullptr, \
+                                  c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -2005,6 +2136,8 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf;
   return 0;
 }
+
+int uvaia_gpu_slice_buffers(void) { return NBUF; }
 
 int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start)
 { return c ? uvaia_gpu_slice_replay_range(c, buf, ordinal0, 0, c->nq, stripe_start) : UVAIA_GPU_EINVAL; }

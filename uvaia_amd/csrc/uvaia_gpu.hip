@@ -86,10 +86,12 @@ struct uvaia_gpu_ctx {
                                  // scan2v_kernel (UVAIA_GPU_SCAN=sgpr|lds), kept for A/B measurements
   // column-compressed scan: classes of the alignment columns for this query set, compressed/dirty query planes, derived reference planes
   uint32_t *d_cls = nullptr;     // [W4*4][4]  cL, cH, constMask, polyMask
-  uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][4][4]   compressed polymorphic columns of the queries (L, H, I, -)
+  uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][L,H,I,-][4]   compressed polymorphic columns of the queries
   uint32_t *d_qc = nullptr;      // [nq_pad][W4][4][2]    ~qI & constMask, ~qV (default) / ~qI (--acgt)
   uint32_t *d_flags = nullptr;   // [nq_pad/16][W4]  bit q: query q of the tile is dirty on constant columns, bit 16+q: on validity
   int NP = 0, NP4 = 0;
+  int need_e_groups = 0, need_v_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
+  int scan_parts = 3;            // timing experiments only (UVAIA_GPU_SCAN_PARTS): bit 0 = polymorphic loop, bit 1 = constant/validity loop
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
@@ -605,13 +607,13 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 // non-ACGT / invalid sites take away on the constant columns / from the valid count (dirty word groups only).
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
 // flags[qtile][w4]    : bit q = query q of the tile is not all-ACGT on a constant column in this word group, bit 16+q = not all valid
-// qc[q][w4][2][4]     : ~qI & constMask (4 words), ~qV (default) / ~qI (--acgt) (4 words)   qpl[q][p4][j][4]: compressed L, H, I
+// qc[q][w4][2][4]     : ~qI & constMask (4 words), ~qV (default) / ~qI (--acgt) (4 words)   qpl[q][p4][L,H,I,-][4]: compressed planes
 template <int QT, bool ACGT>
-__global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
                                                      int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ qc,
                                                      const uint32_t *__restrict__ flags, const int *__restrict__ tot_e, const int *__restrict__ tot_v,
                                                      int2 *__restrict__ out, int ppad, int n_qtiles, int *__restrict__ tmin, int r_lo, int r_hi,
-                                                     int *__restrict__ mp_out)
+                                                     int *__restrict__ mp_out, int parts)
 {
   static_assert(QT == 16, "flag words are laid out for tiles of 16 queries");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev
 #pragma unroll
   for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = acc[q][2] = 0; }
   // ---- polymorphic columns, dense
-  {
+  if (parts & 1) {
     const uint4 *t = poly + (size_t)(tile_first + trel) * NP4 * 3 * 64 + lane;
     const size_t qstride = (size_t)NP4 * 16;
     const uint32_t *qb = qpl + (size_t)q0 * qstride;
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev
       const uint4 pL = t[(size_t)(p4 * 3 + 0) * 64], pH = t[(size_t)(p4 * 3 + 1) * 64], pI = t[(size_t)(p4 * 3 + 2) * 64];
       const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
       const uint32_t *s0 = qb + (size_t)p4 * 16;
-      QWords<16> cur, nxt;
+      QWords<12> cur, nxt;                                  // L[4], H[4], I[4] of the group: one s_load_dwordx8 + one x4
       load_qwords(cur, s0);
 #pragma unroll
       for (int q = 0; q < QT; q++) {
@@ -640,57 +642,75 @@ __global__ __launch_bounds__(256) void scan3_kernel(const uint4 *__restrict__ ev
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const uint32_t d = rL[j] ^ cur.v[j * 4 + 0];
-          const uint32_t y = B3(rH[j], cur.v[j * 4 + 1], d, (TT_A ^ TT_B) | TT_C);
-          acc[q][0] = bcnt_acc(ACGT ? B3(y, rI[j], cur.v[j * 4 + 2], TT_A & TT_B & TT_C) : B3(y, rI[j], cur.v[j * 4 + 2], ~TT_A & TT_B & TT_C), acc[q][0]);
+          const uint32_t d = rL[j] ^ cur.v[j];
+          const uint32_t y = B3(rH[j], cur.v[4 + j], d, (TT_A ^ TT_B) | TT_C);
+          // --acgt: mismatches, kept apart (they are also dist_unique).  default: NON-matches (padding bits included), so that one
+          // accumulator serves both loops: matches = te + 128 NP4 - (non-matches here + what the dirty words take away)
+          if (ACGT) acc[q][0] = bcnt_acc(B3(y, rI[j], cur.v[8 + j], TT_A & TT_B & TT_C), acc[q][0]);
+          else      acc[q][1] = bcnt_acc(B3(y, rI[j], cur.v[8 + j], ~(~TT_A & TT_B & TT_C)), acc[q][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < QT) cur = nxt;
       }
     }
   }
+  const size_t r = (size_t)trel * 64 + lane;
+  if (ACGT) {     // mismatches on the polymorphic columns are an output of their own (dist_unique): park them there, their registers are free
+#pragma unroll  // for the second loop, and read them back (L2) for the total at the end
+    for (int q = 0; q < QT; q++) mp_out[(size_t)(q0 + q) * ppad + r] = acc[q][0];
+  }
   // ---- constant columns and validity: only where a query is dirty.  One flag dword per word group: bit q = query q of the
   // tile is not all-ACGT on a constant column here, bit 16+q = it has an invalid site here; every test is one scalar bit test.
-  {
+  if (parts & 2) {
     const uint4 *t = ev + (size_t)(tile_first + trel) * W4 * 2 * 64 + lane;
     const uint32_t *fl = flags + (size_t)qtile * W4;
-    const size_t qstride = (size_t)W4 * 8;
-    const uint32_t *qb = qc + (size_t)q0 * qstride;
+    const uint32_t qs32 = (uint32_t)W4 * 8u;
+    const uint32_t *qb = qc + (size_t)q0 * qs32;
     for (int w4 = 0; w4 < W4; w4++) {
       const uint32_t f = fl[w4];
       if (f == 0u) continue;                                             // every query of the tile is clean here
       const uint4 pE = (f & 0xFFFFu) ? t[(size_t)(w4 * 2 + 0) * 64] : make_uint4(0, 0, 0, 0);
       const uint4 pV = (f >> 16) ? t[(size_t)(w4 * 2 + 1) * 64] : make_uint4(0, 0, 0, 0);
       const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
+      // A query is an "item" of this word group if either bit is set: its 8 mask words arrive by one s_load_dwordx8.  The load of
+      // the NEXT item is issued before the counting of the current one (landing registers -> working copy), so the scalar-cache
+      // latency hides behind 16 VALU instructions instead of stalling every item (2.29 -> 1.54 ms per 32 768 x 1 000 launch).
+      const uint32_t fa = (f | (f >> 16)) & 0xFFFFu;
+      const uint32_t *qbw = qb + (size_t)w4 * 8;
+      QWords<8> land;
+      load_qwords(land, qbw + (uint32_t)__builtin_ctz(fa) * qs32);
+      asm volatile("" ::"s"(land.v[0]), "s"(land.v[1]), "s"(land.v[2]), "s"(land.v[3]), "s"(land.v[4]), "s"(land.v[5]), "s"(land.v[6]), "s"(land.v[7]));
 #pragma unroll
       for (int q = 0; q < QT; q++) {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(qb + (size_t)q * qstride + (size_t)w4 * 8);   // [0] ~qI & constMask, [1] ~qV
-        if (f & (1u << q)) {
-          const uint4 sI = s4[0];                                        // one s_load_dwordx4
-          acc[q][1] = bcnt_acc(rE[0] & sI.x, acc[q][1]); acc[q][1] = bcnt_acc(rE[1] & sI.y, acc[q][1]);
-          acc[q][1] = bcnt_acc(rE[2] & sI.z, acc[q][1]); acc[q][1] = bcnt_acc(rE[3] & sI.w, acc[q][1]);
-        }
-        if (f & (0x10000u << q)) {
-          const uint4 sV = s4[1];
-          acc[q][2] = bcnt_acc(rV[0] & sV.x, acc[q][2]); acc[q][2] = bcnt_acc(rV[1] & sV.y, acc[q][2]);
-          acc[q][2] = bcnt_acc(rV[2] & sV.z, acc[q][2]); acc[q][2] = bcnt_acc(rV[3] & sV.w, acc[q][2]);
+        if (fa & (1u << q)) {
+          const QWords<8> wk = land;                                       // [0..3] ~qI & constMask, [4..7] ~qV
+          const uint32_t rem = fa & ~((2u << q) - 1u);
+          const uint32_t qn = rem ? (uint32_t)__builtin_ctz(rem) : (uint32_t)q;
+          load_qwords(land, qbw + qn * qs32);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[q][1] = bcnt_acc(rE[j] & wk.v[j], acc[q][1]);
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[q][2] = bcnt_acc(rV[j] & wk.v[4 + j], acc[q][2]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
   }
-  const size_t r = (size_t)trel * 64 + lane;
   const int te = tot_e[r], tv = tot_v[r];
   const bool in_batch = ((int)r >= r_lo && (int)r < r_hi);
+  const int *mp_in = mp_out;
+  asm volatile("" : "+s"(mp_in));          // recompute the addresses here instead of keeping 16 of them alive across the loop above
 #pragma unroll
   for (int q = 0; q < QT; q++) {
-    const int c0 = acc[q][0] + te - acc[q][1], c1 = tv - acc[q][2];
+    const int c0 = (ACGT ? mp_in[(size_t)(q0 + q) * ppad + r] + te : te + NP4 * 128) - acc[q][1], c1 = tv - acc[q][2];
     out[(size_t)(q0 + q) * ppad + r] = make_int2(c0, c1);
-    if (ACGT) mp_out[(size_t)(q0 + q) * ppad + r] = acc[q][0];      // mismatches on the polymorphic columns = dist_unique
     // smallest mismatch count of the tile: lets the replay skip tiles that cannot pass the gate (src/nearest.c:488) at all
     int m = in_batch ? (ACGT ? c0 : c1 - c0) : 0x7fffffff;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
     if (lane == 0) tmin[(size_t)(q0 + q) * (ppad >> 6) + trel] = m;
+    __builtin_amdgcn_sched_barrier(0);                                // one query at a time: keeps the epilogue from inflating the register budget
   }
 }
 
@@ -1459,8 +1479,8 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const int nqt3 = (c->nq + 15) / 16;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp);
+if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1738,8 +1758,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           const uint32_t qL = real ? QL(i, w, 0) : 0u, qH = real ? QL(i, w, 1) : 0u, qI = real ? QL(i, w, 2) : 0u, qV = real ? QL(i, w, 3) : 0u;
           for (uint32_t m = cls[(size_t)w * 4 + 3]; m; m &= m - 1, k++) {
             const int b = __builtin_ctz(m);
-            uint32_t *d = qpl.data() + (size_t)i * prow + (size_t)(k >> 5) * 4;
-            d[0] |= ((qL >> b) & 1u) << (k & 31); d[1] |= ((qH >> b) & 1u) << (k & 31); d[2] |= ((qI >> b) & 1u) << (k & 31);
+            uint32_t *d = qpl.data() + (size_t)i * prow + (size_t)(k >> 7) * 16 + ((k >> 5) & 3);     // [p4][L,H,I,-][word of the group]
+            d[0] |= ((qL >> b) & 1u) << (k & 31); d[4] |= ((qH >> b) & 1u) << (k & 31); d[8] |= ((qI >> b) & 1u) << (k & 31);
           }
           const uint32_t nI = ~qI & cls[(size_t)w * 4 + 2], nV = ~qV;
           qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + (w & 3)] = nI; qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + 4 + (w & 3)] = nV;
@@ -1748,6 +1768,12 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           if (real && nV) fw |= 0x10000u << (i % 16);
         }
       }
+      for (int g = 0; g < c->W4; g++) {
+        uint32_t u = 0;
+        for (int t = 0; t < c->nq_pad / 16; t++) u |= flg[(size_t)t * c->W4 + g];
+        c->need_e_groups += (u & 0xFFFFu) != 0; c->need_v_groups += (u >> 16) != 0;
+      }
+      { const char *ep = getenv("UVAIA_GPU_SCAN_PARTS"); if (ep) c->scan_parts = atoi(ep); }
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qc, qcv.size() * 4)); OPENCHK(hipMemcpy(c->d_qc, qcv.data(), qcv.size() * 4, hipMemcpyHostToDevice));
@@ -1830,9 +1856,11 @@ int uvaia_gpu_heap_slots(const uvaia_gpu_ctx *c) { return c ? c->k : 0; }
 int uvaia_gpu_n_query(const uvaia_gpu_ctx *c) { return c ? c->nq : 0; }
 size_t uvaia_gpu_packed_bytes_per_ref(const uvaia_gpu_ctx *c) { return c ? (size_t)c->W4 * 16 * c->P : 0; }
 size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
-{ // what the default scan reads per reference: two derived planes over the whole alignment + three planes of the gathered polymorphic columns
+{ // distinct bytes of a reference the default scan has to read at least once: the word groups of the two derived planes that
+  // some query tile needs (groups where every query is clean are never loaded) + three planes of the gathered polymorphic columns
   if (!c) return 0;
-  return (c->fullscan || c->scan_variant != 2) ? (size_t)c->W4 * 16 * c->P : (size_t)c->W4 * 16 * 2 + (size_t)c->NP4 * 16 * 3;
+  return (c->fullscan || c->scan_variant != 2) ? (size_t)c->W4 * 16 * c->P
+                                                : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->NP4 * 16 * 3;
 }
 
 int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)

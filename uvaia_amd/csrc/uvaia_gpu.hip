@@ -87,12 +87,13 @@ struct uvaia_gpu_ctx {
   // column-compressed scan: classes of the alignment columns for this query set, compressed/dirty query planes, derived reference planes
   uint32_t *d_cls = nullptr;     // [W4*4][4]  cL, cH, constMask, polyMask
   uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][L,H,I,-][4]   compressed polymorphic columns of the queries
-  uint32_t *d_qc = nullptr;      // [nq_pad][W4][4][2]    ~qI & constMask, ~qV (default) / ~qI (--acgt)
-  uint32_t *d_flags = nullptr;   // [nq_pad/16][W4]  bit q: query q of the tile is dirty on constant columns, bit 16+q: on validity
+  uint32_t *d_stream = nullptr;  // per query tile: the dirty-word item stream of scan3_kernel (layout: see the kernel)
+  uint2 *d_sdir = nullptr;       // [nq_pad/16] {first dword of the tile's stream, number of group records}
   int NP = 0, NP4 = 0;
-  int need_e_groups = 0, need_v_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
+  int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int scan_parts = 3;            // timing experiments only (UVAIA_GPU_SCAN_PARTS): bit 0 = polymorphic loop, bit 1 = constant/validity loop
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
+  uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
 // device: the pair scan (dominant kernel)
 // ------------------------------------------------------------------------------------------------------------
 template <int N> struct QWords { uint32_t v[N]; };
-template <int N> static __device__ __forceinline__ void load_qwords(QWords<N> &d, const uint32_t *__restrict__ p)
+template <int N, typename PTR> static __device__ __forceinline__ void load_qwords(QWords<N> &d, PTR p)
 {
 #pragma unroll
   for (int i = 0; i < N; i++) d.v[i] = p[i];   // wave-uniform address -> s_load_dwordx8/x16
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void scan2_acgt_kernel(const uint4 *__restrict
 template <bool ACGT>
 __global__ __launch_bounds__(256) void derive_ev_kernel(const uint4 *__restrict__ tiles, long long tile_base, int W4,
                                                          const uint32_t *__restrict__ cls /*[W4*4][4]: cL, cH, constMask, polyMask*/,
-                                                         uint4 *__restrict__ ev, int *__restrict__ tot_e)
+                                                         uint4 *__restrict__ ev, int *__restrict__ tot_e, uint32_t *__restrict__ grp)
 {
   constexpr int P = ACGT ? 3 : 4;
   __shared__ int partial[4][64];
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(256) void derive_ev_kernel(const uint4 *__restrict_
   for (int w4 = wv; w4 < W4; w4 += 4) {
     const uint4 p0 = t[(size_t)(w4 * P + 0) * 64], p1 = t[(size_t)(w4 * P + 1) * 64], p2 = t[(size_t)(w4 * P + 2) * 64], p3 = t[(size_t)(w4 * P + (P - 1)) * 64];
     uint32_t e[4], v[4];
+    int ge = 0, gv = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       uint32_t rL, rH, rI, rV;
@@ -539,8 +541,10 @@ __global__ __launch_bounds__(256) void derive_ev_kernel(const uint4 *__restrict_
       const uint32_t diff = (rL ^ c4[0]) | (rH ^ c4[1]);
       e[j] = rI & c4[2] & (ACGT ? diff : ~diff);
       v[j] = rV;
-      te += __popc(e[j]);
+      ge += __popc(e[j]); gv += __popc(v[j]);
     }
+    te += ge;
+    grp[((size_t)tile * W4 + w4) * 64 + lane] = (uint32_t)ge | ((uint32_t)gv << 16);
     o[(size_t)(w4 * 2 + 0) * 64] = make_uint4(e[0], e[1], e[2], e[3]);
     o[(size_t)(w4 * 2 + 1) * 64] = make_uint4(v[0], v[1], v[2], v[3]);
   }
@@ -603,99 +607,137 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
   while (ow & 3) { fill = 32; flush_word(); }                          // pad the last group with zero words
 }
 
-// scan over the derived planes: acc0 = dense count on the compressed polymorphic words, acc1/acc2 = what the query's
-// non-ACGT / invalid sites take away on the constant columns / from the valid count (dirty word groups only).
+// scan over the derived planes.  Two loops per (16 queries x 64 references) pass of a wave:
+//  1. polymorphic columns, dense: static 16-query unroll, counts in VGPRs, query words by scalar loads (VALU-bound);
+//  2. constant columns + validity: only where a query is "dirty".  Measured (profiles/r01_issue_rate_microbench.txt): a CU
+//     issues ONE scalar-ALU instruction per cycle for all four SIMDs, and VALU + SALU together ~1.9 per cycle, so a statically
+//     unrolled chain of per-query bit tests is bound by its scalar bookkeeping, not by the popcounts.  The dirty work is
+//     therefore a precomputed, query-tile-specific ITEM STREAM walked by a dynamic loop: every item carries its eight mask
+//     words and the LDS offset of its query's counter, the counters (two u16 halves in one dword: constant-column deficit |
+//     validity deficit << 16) live in LDS and take one ds_add_u32 per item, and a query that is N/gap over a whole 128-column
+//     group costs a single ds_add of the reference's own per-group counts (grp[]).
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
-// flags[qtile][w4]    : bit q = query q of the tile is not all-ACGT on a constant column in this word group, bit 16+q = not all valid
-// qc[q][w4][2][4]     : ~qI & constMask (4 words), ~qV (default) / ~qI (--acgt) (4 words)   qpl[q][p4][L,H,I,-][4]: compressed planes
+// stream (dwords), per query tile, sdir[qtile] = {first dword, number of group records}:
+//   record = { w4 | needE << 16 | needV << 17,  n_full,  n_generic,  0 }  + n_full LDS offsets (padded to a multiple of 4)
+//            + n_generic x { ~qI & constMask [4],  ~qV (default) / ~qI (--acgt) [4],  LDS offset, 0, 0, 0 }
+// qpl[q][p4][L,H,I,-][4]: compressed planes of the polymorphic columns
 template <int QT, bool ACGT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
-                                                     int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ qc,
-                                                     const uint32_t *__restrict__ flags, const int *__restrict__ tot_e, const int *__restrict__ tot_v,
+                                                     int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ stream,
+                                                     const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
+                                                     const int *__restrict__ tot_e, const int *__restrict__ tot_v,
                                                      int2 *__restrict__ out, int ppad, int n_qtiles, int *__restrict__ tmin, int r_lo, int r_hi,
                                                      int *__restrict__ mp_out, int parts)
 {
-  static_assert(QT == 16, "flag words are laid out for tiles of 16 queries");
+  static_assert(QT == 16, "stream offsets are laid out for tiles of 16 queries");
+  __shared__ uint32_t lacc[4][QT][64];                         // per wave: one packed counter per (query, lane)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int qtile, group;
   if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
   const int trel = group * 4 + wave;
   if (trel >= n_tiles) return;
   const int q0 = qtile * QT;
-  int acc[QT][3];
+  const size_t r = (size_t)trel * 64 + lane;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;   // explicit LDS pointer: the stream loads stay scalar (no may-alias with the atomics)
+  lds_u32 *my = (lds_u32 *)&lacc[wave][0][lane];
+  {
+    int acc[QT];
 #pragma unroll
-  for (int q = 0; q < QT; q++) { acc[q][0] = acc[q][1] = acc[q][2] = 0; }
-  // ---- polymorphic columns, dense
-  if (parts & 1) {
-    const uint4 *t = poly + (size_t)(tile_first + trel) * NP4 * 3 * 64 + lane;
-    const size_t qstride = (size_t)NP4 * 16;
-    const uint32_t *qb = qpl + (size_t)q0 * qstride;
-    for (int p4 = 0; p4 < NP4; p4++) {
-      const uint4 pL = t[(size_t)(p4 * 3 + 0) * 64], pH = t[(size_t)(p4 * 3 + 1) * 64], pI = t[(size_t)(p4 * 3 + 2) * 64];
-      const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
-      const uint32_t *s0 = qb + (size_t)p4 * 16;
-      QWords<12> cur, nxt;                                  // L[4], H[4], I[4] of the group: one s_load_dwordx8 + one x4
-      load_qwords(cur, s0);
+    for (int q = 0; q < QT; q++) acc[q] = 0;
+    // ---- polymorphic columns, dense
+    if (parts & 1) {
+      const uint4 *t = poly + (size_t)(tile_first + trel) * NP4 * 3 * 64 + lane;
+      const size_t qstride = (size_t)NP4 * 16;
+      const uint32_t *qb = qpl + (size_t)q0 * qstride;
+      for (int p4 = 0; p4 < NP4; p4++) {
+        const uint4 pL = t[(size_t)(p4 * 3 + 0) * 64], pH = t[(size_t)(p4 * 3 + 1) * 64], pI = t[(size_t)(p4 * 3 + 2) * 64];
+        const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
+        const uint32_t *s0 = qb + (size_t)p4 * 16;
+        QWords<12> cur, nxt;                                  // L[4], H[4], I[4] of the group: one s_load_dwordx8 + one x4
+        load_qwords(cur, s0);
 #pragma unroll
-      for (int q = 0; q < QT; q++) {
-        if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < QT; q++) {
+          if (q + 1 < QT) load_qwords(nxt, s0 + (size_t)(q + 1) * qstride);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t d = rL[j] ^ cur.v[j];
-          const uint32_t y = B3(rH[j], cur.v[4 + j], d, (TT_A ^ TT_B) | TT_C);
-          // --acgt: mismatches, kept apart (they are also dist_unique).  default: NON-matches (padding bits included), so that one
-          // accumulator serves both loops: matches = te + 128 NP4 - (non-matches here + what the dirty words take away)
-          if (ACGT) acc[q][0] = bcnt_acc(B3(y, rI[j], cur.v[8 + j], TT_A & TT_B & TT_C), acc[q][0]);
-          else      acc[q][1] = bcnt_acc(B3(y, rI[j], cur.v[8 + j], ~(~TT_A & TT_B & TT_C)), acc[q][1]);
+          for (int j = 0; j < 4; j++) {
+            const uint32_t d = rL[j] ^ cur.v[j];
+            const uint32_t y = B3(rH[j], cur.v[4 + j], d, (TT_A ^ TT_B) | TT_C);
+            // --acgt: mismatches (they are also dist_unique).  default: NON-matches (padding bits included), which start the
+            // constant-column deficit:  matches = te + 128 NP4 - (non-matches here + what the dirty words take away)
+            acc[q] = bcnt_acc(ACGT ? B3(y, rI[j], cur.v[8 + j], TT_A & TT_B & TT_C) : B3(y, rI[j], cur.v[8 + j], ~(~TT_A & TT_B & TT_C)), acc[q]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 1 < QT) cur = nxt;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + 1 < QT) cur = nxt;
       }
     }
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      if (ACGT) { mp_out[(size_t)(q0 + q) * ppad + r] = acc[q]; my[q * 64] = 0u; }
+      else my[q * 64] = (uint32_t)acc[q];
+    }
   }
-  const size_t r = (size_t)trel * 64 + lane;
-  if (ACGT) {     // mismatches on the polymorphic columns are an output of their own (dist_unique): park them there, their registers are free
-#pragma unroll  // for the second loop, and read them back (L2) for the total at the end
-    for (int q = 0; q < QT; q++) mp_out[(size_t)(q0 + q) * ppad + r] = acc[q][0];
-  }
-  // ---- constant columns and validity: only where a query is dirty.  One flag dword per word group: bit q = query q of the
-  // tile is not all-ACGT on a constant column here, bit 16+q = it has an invalid site here; every test is one scalar bit test.
+  // ---- constant columns and validity: the item stream of this query tile
   if (parts & 2) {
     const uint4 *t = ev + (size_t)(tile_first + trel) * W4 * 2 * 64 + lane;
-    const uint32_t *fl = flags + (size_t)qtile * W4;
-    const uint32_t qs32 = (uint32_t)W4 * 8u;
-    const uint32_t *qb = qc + (size_t)q0 * qs32;
-    for (int w4 = 0; w4 < W4; w4++) {
-      const uint32_t f = fl[w4];
-      if (f == 0u) continue;                                             // every query of the tile is clean here
-      const uint4 pE = (f & 0xFFFFu) ? t[(size_t)(w4 * 2 + 0) * 64] : make_uint4(0, 0, 0, 0);
-      const uint4 pV = (f >> 16) ? t[(size_t)(w4 * 2 + 1) * 64] : make_uint4(0, 0, 0, 0);
-      const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
-      // A query is an "item" of this word group if either bit is set: its 8 mask words arrive by one s_load_dwordx8.  The load of
-      // the NEXT item is issued before the counting of the current one (landing registers -> working copy), so the scalar-cache
-      // latency hides behind 16 VALU instructions instead of stalling every item (2.29 -> 1.54 ms per 32 768 x 1 000 launch).
-      const uint32_t fa = (f | (f >> 16)) & 0xFFFFu;
-      const uint32_t *qbw = qb + (size_t)w4 * 8;
-      QWords<8> land;
-      load_qwords(land, qbw + (uint32_t)__builtin_ctz(fa) * qs32);
-      asm volatile("" ::"s"(land.v[0]), "s"(land.v[1]), "s"(land.v[2]), "s"(land.v[3]), "s"(land.v[4]), "s"(land.v[5]), "s"(land.v[6]), "s"(land.v[7]));
-#pragma unroll
-      for (int q = 0; q < QT; q++) {
-        if (fa & (1u << q)) {
-          const QWords<8> wk = land;                                       // [0..3] ~qI & constMask, [4..7] ~qV
-          const uint32_t rem = fa & ~((2u << q) - 1u);
-          const uint32_t qn = rem ? (uint32_t)__builtin_ctz(rem) : (uint32_t)q;
-          load_qwords(land, qbw + qn * qs32);
+    const uint32_t *gt = grp + (size_t)(tile_first + trel) * W4 * 64 + lane;
+    const uint2 dir = sdir[qtile];
+    typedef __attribute__((address_space(4))) const uint32_t cst_u32;   // constant address space: uniform loads from it are scalar loads
+    const cst_u32 *sp = (const cst_u32 *)(stream + dir.x);
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char *myc = (lds_char *)my;
+#define LDS_ADD(byte_off, val) __hip_atomic_fetch_add((lds_u32 *)(myc + (byte_off)), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define COUNT_ITEM(it)                                                                                              \
+    {                                                                                                               \
+      int e_ = 0, v_ = 0;                                                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) e_ = bcnt_acc(rE[j] & it.v[j], e_);                             \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) v_ = bcnt_acc(rV[j] & it.v[4 + j], v_);                         \
+      LDS_ADD(it.v[8], (uint32_t)e_ | ((uint32_t)v_ << 16));                                                        \
+    }
+#define TOUCH_ITEM(it) asm volatile("" ::"s"(it.v[0]), "s"(it.v[1]), "s"(it.v[2]), "s"(it.v[3]), "s"(it.v[4]), "s"(it.v[5]), "s"(it.v[6]), "s"(it.v[7]), "s"(it.v[8]))
+    for (uint32_t rec = 0; rec < dir.y; rec++) {
+      QWords<4> h;
+      load_qwords(h, sp);
+      const uint32_t h0 = h.v[0], n_full = h.v[1], n_gen = h.v[2];
+      const uint32_t w4 = h0 & 0xFFFFu;
+      sp += 4;
+      uint4 pE = make_uint4(0, 0, 0, 0), pV = pE;
+      if (h0 & 0x10000u) pE = t[(size_t)(w4 * 2 + 0) * 64];
+      if (h0 & 0x20000u) pV = t[(size_t)(w4 * 2 + 1) * 64];
+      if (n_full) {     // all-N queries: what they take away is the reference's own count for the group (same packing as the counters)
+        const uint32_t g = gt[(size_t)w4 * 64];
+        for (uint32_t k = 0; k < n_full; k++) LDS_ADD(sp[k], g);
+        sp += (n_full + 3u) & ~3u;
+      }
+      if (n_gen) {
+        const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
+        // two items in flight: the words of the next one arrive while the current one is counted.  TOUCH_ITEM pins the wait for
+        // a prefetched item BEFORE the following prefetch is issued (scalar loads return out of order: the only wait is "all").
+        QWords<9> a, b;
+        load_qwords(a, sp);
+        TOUCH_ITEM(a);
+        for (uint32_t k = 0; k < n_gen; k += 2) {
+          load_qwords(b, sp + 12);       // the stream is padded: reading past the last item is harmless
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[q][1] = bcnt_acc(rE[j] & wk.v[j], acc[q][1]);
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[q][2] = bcnt_acc(rV[j] & wk.v[4 + j], acc[q][2]);
+          COUNT_ITEM(a);
           __builtin_amdgcn_sched_barrier(0);
+          TOUCH_ITEM(b);
+          if (k + 1 < n_gen) {
+            load_qwords(a, sp + 24);
+            __builtin_amdgcn_sched_barrier(0);
+            COUNT_ITEM(b);
+            __builtin_amdgcn_sched_barrier(0);
+            TOUCH_ITEM(a);
+          }
+          sp += 24;
         }
+        if (n_gen & 1u) sp -= 12;
       }
     }
+#undef LDS_ADD
+#undef COUNT_ITEM
+#undef TOUCH_ITEM
   }
   const int te = tot_e[r], tv = tot_v[r];
   const bool in_batch = ((int)r >= r_lo && (int)r < r_hi);
@@ -703,7 +745,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   asm volatile("" : "+s"(mp_in));          // recompute the addresses here instead of keeping 16 of them alive across the loop above
 #pragma unroll
   for (int q = 0; q < QT; q++) {
-    const int c0 = (ACGT ? mp_in[(size_t)(q0 + q) * ppad + r] + te : te + NP4 * 128) - acc[q][1], c1 = tv - acc[q][2];
+    const uint32_t pk = my[q * 64];
+    const int c0 = (ACGT ? mp_in[(size_t)(q0 + q) * ppad + r] + te : te + NP4 * 128) - (int)(pk & 0xFFFFu), c1 = tv - (int)(pk >> 16);
     out[(size_t)(q0 + q) * ppad + r] = make_int2(c0, c1);
     // smallest mismatch count of the tile: lets the replay skip tiles that cannot pass the gate (src/nearest.c:488) at all
     int m = in_batch ? (ACGT ? c0 : c1 - c0) : 0x7fffffff;
@@ -1477,10 +1520,11 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const bool is_db = (tiles == c->d_db);
     const uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
+    const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const int nqt3 = (c->nq + 15) / 16;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_qc, c->d_flags, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
+    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1590,13 +1634,14 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
     const bool is_db = (tiles == c->d_db);
     uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
     int *tote = is_db ? c->d_db_tote : c->d_batch_tote;
+    uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
     const int nblk = (int)(t1 - t0 + 1);
     if (c->acgt) {
-      hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote);
+      hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
       if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
     } else {
-      hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote);
+      hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
       if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
     }
     HIPCHK(c, hipGetLastError());
@@ -1626,7 +1671,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_cls, c->d_qpl, c->d_qc, c->d_flags, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
@@ -1750,9 +1795,10 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       }
       c->NP4 = ((c->NP + 31) / 32 + 3) / 4;
       const size_t prow = (size_t)std::max(c->NP4, 1) * 16, crow = (size_t)c->W4 * 8;
-      std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4, 0u);
+      std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4 * 2, 0u);
       for (int i = 0; i < c->nq_pad; i++) {
         int k = 0;                                                   // compressed bit position
+        bool full = false;                                           // all 128 columns of the current word group are N/gap
         for (int w = 0; w < Wp; w++) {
           const bool real = i < c->nq;
           const uint32_t qL = real ? QL(i, w, 0) : 0u, qH = real ? QL(i, w, 1) : 0u, qI = real ? QL(i, w, 2) : 0u, qV = real ? QL(i, w, 3) : 0u;
@@ -1763,21 +1809,49 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           }
           const uint32_t nI = ~qI & cls[(size_t)w * 4 + 2], nV = ~qV;
           qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + (w & 3)] = nI; qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + 4 + (w & 3)] = nV;
-          uint32_t &fw = flg[(size_t)(i / 16) * c->W4 + (w >> 2)];
-          if (real && nI) fw |= 1u << (i % 16);          // padding queries of the last tile are never read back: keep them "clean"
-          if (real && nV) fw |= 0x10000u << (i % 16);
+          uint32_t *fw = &flg[((size_t)(i / 16) * c->W4 + (w >> 2)) * 2];
+          if (real && nI) fw[0] |= 1u << (i % 16);       // padding queries of the last tile are never read back: keep them "clean"
+          if (real && nV) fw[0] |= 0x10000u << (i % 16);
+          if ((w & 3) == 0) full = real;
+          full = full && nI == cls[(size_t)w * 4 + 2] && nV == 0xFFFFFFFFu;
+          if ((w & 3) == 3 && full) { fw[0] &= ~(0x10001u << (i % 16)); fw[1] |= 1u << (i % 16); }
         }
       }
       for (int g = 0; g < c->W4; g++) {
         uint32_t u = 0;
-        for (int t = 0; t < c->nq_pad / 16; t++) u |= flg[(size_t)t * c->W4 + g];
-        c->need_e_groups += (u & 0xFFFFu) != 0; c->need_v_groups += (u >> 16) != 0;
+        uint32_t uy = 0;
+        for (int t = 0; t < c->nq_pad / 16; t++) { u |= flg[((size_t)t * c->W4 + g) * 2]; uy |= flg[((size_t)t * c->W4 + g) * 2 + 1]; }
+        c->need_e_groups += (u & 0xFFFFu) != 0; c->need_v_groups += (u >> 16) != 0; c->need_g_groups += uy != 0;
       }
       { const char *ep = getenv("UVAIA_GPU_SCAN_PARTS"); if (ep) c->scan_parts = atoi(ep); }
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
-      OPENCHK(hipMalloc(&c->d_qc, qcv.size() * 4)); OPENCHK(hipMemcpy(c->d_qc, qcv.data(), qcv.size() * 4, hipMemcpyHostToDevice));
-      OPENCHK(hipMalloc(&c->d_flags, flg.size() * 4)); OPENCHK(hipMemcpy(c->d_flags, flg.data(), flg.size() * 4, hipMemcpyHostToDevice));
+      // the item stream of every query tile (layout: see scan3_kernel)
+      std::vector<uint32_t> strm, sdir((size_t)(c->nq_pad / 16) * 2, 0u);
+      for (int t = 0; t < c->nq_pad / 16; t++) {
+        sdir[(size_t)t * 2] = (uint32_t)strm.size();
+        uint32_t nrec = 0;
+        for (int g = 0; g < c->W4; g++) {
+          const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
+          if ((fx | fy) == 0u) continue;
+          const uint32_t fa = (fx | (fx >> 16)) & 0xFFFFu;
+          strm.push_back((uint32_t)g | ((fx & 0xFFFFu) ? 0x10000u : 0u) | ((fx >> 16) ? 0x20000u : 0u));
+          strm.push_back((uint32_t)__builtin_popcount(fy)); strm.push_back((uint32_t)__builtin_popcount(fa)); strm.push_back(0u);
+          for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * 256u);
+          while (strm.size() & 3) strm.push_back(0u);
+          for (uint32_t m = fa; m; m &= m - 1) {
+            const int q = __builtin_ctz(m);
+            const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
+            strm.insert(strm.end(), src, src + 8);
+            strm.push_back((uint32_t)q * 256u); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
+          }
+          nrec++;
+        }
+        sdir[(size_t)t * 2 + 1] = nrec;
+      }
+      strm.resize(strm.size() + 64, 0u);                                // the kernel prefetches one item past the end
+      OPENCHK(hipMalloc(&c->d_stream, strm.size() * 4)); OPENCHK(hipMemcpy(c->d_stream, strm.data(), strm.size() * 4, hipMemcpyHostToDevice));
+      OPENCHK(hipMalloc(&c->d_sdir, sdir.size() * 4)); OPENCHK(hipMemcpy(c->d_sdir, sdir.data(), sdir.size() * 4, hipMemcpyHostToDevice));
     }
     OPENCHK(hipMalloc(&c->d_amb_q, ambq.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_amb_q, ambq.data(), ambq.size() * sizeof(int), hipMemcpyHostToDevice));
   }
@@ -1802,6 +1876,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_ev, (c->pool_pad / 64) * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
+  OPENCHK(hipMalloc(&c->d_batch_grp, (c->pool_pad / 64) * (size_t)c->W4 * 64 * sizeof(uint32_t)));
   OPENCHK(hipMalloc(&c->d_batch_poly, (c->pool_pad / 64) * (size_t)std::max(c->NP4, 1) * 3 * 64 * sizeof(uint4)));
   OPENCHK(hipMalloc(&c->d_batch_tote, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
@@ -1860,7 +1935,7 @@ size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
   // some query tile needs (groups where every query is clean are never loaded) + three planes of the gathered polymorphic columns
   if (!c) return 0;
   return (c->fullscan || c->scan_variant != 2) ? (size_t)c->W4 * 16 * c->P
-                                                : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->NP4 * 16 * 3;
+                                                : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->need_g_groups * 4 + (size_t)c->NP4 * 16 * 3;
 }
 
 int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
@@ -1911,7 +1986,7 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   if (!c) return UVAIA_GPU_EINVAL;
   if (cap <= c->db_cap) return 0;
   if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "reserve the database before appending to it");
-  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); hipFree(c->d_db_tot); hipFree(c->d_db_ev); hipFree(c->d_db_poly); hipFree(c->d_db_tote);
+  if (c->d_db) { hipFree(c->d_db); hipFree(c->d_db_nonn); hipFree(c->d_db_amb); hipFree(c->d_db_tot); hipFree(c->d_db_ev); hipFree(c->d_db_poly); hipFree(c->d_db_tote); hipFree(c->d_db_grp); c->d_db_grp = nullptr;
                  c->d_db = nullptr; c->d_db_nonn = nullptr; c->d_db_amb = nullptr; c->d_db_tot = nullptr; c->d_db_ev = c->d_db_poly = nullptr; c->d_db_tote = nullptr; }
   const size_t tiles = (cap + 63) / 64 + 1, tile_u4 = (size_t)c->W4 * c->P * 64;
   HIPCHK(c, hipMalloc(&c->d_db, tiles * tile_u4 * sizeof(uint4)));
@@ -1919,6 +1994,7 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   HIPCHK(c, hipMalloc(&c->d_db_nonn, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_ev, tiles * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_grp, tiles * (size_t)c->W4 * 64 * sizeof(uint32_t)));
   HIPCHK(c, hipMalloc(&c->d_db_poly, tiles * (size_t)std::max(c->NP4, 1) * 3 * 64 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_tote, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_tot, tiles * 64 * sizeof(int)));

@@ -1,0 +1,16 @@
+#!/bin/bash
+# One measurement pass on the GPU box; everything lands in gpurun_out/measure/.  Usage: bash tools/measure_round.sh
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/measure; mkdir -p $O
+step() { echo "== $*"; }
+step bench config1;  timeout -k 10 400 python bench.py --steps 5 --warmup 1 > $O/bench_c2.json 2> $O/bench_c2.err || exit 1
+step kernel stats;   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o c2 --output-format csv -- python bench.py --steps 5 --warmup 1 --cpu-refs 0 > $O/stats.log 2>&1 || exit 1
+step pmc fetch;      timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_fetch.log 2>&1 || exit 1
+step pmc write;      timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_write.log 2>&1 || exit 1
+step pmc fetch q4;   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_q4 -o f --output-format csv -- python bench.py --queries 4 --refs 1000000 --pool 1000000 --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_fetch_q4.log 2>&1 || exit 1
+for q in 1 4 16 64; do step sweep q=$q; timeout -k 10 300 python bench.py --queries $q --refs 1000000 --pool 1000000 --steps 5 --warmup 1 --cpu-refs 0 > $O/sweep_q$q.json 2> $O/sweep_q$q.err || exit 1; done
+step acgt config1;   timeout -k 10 300 python bench.py --mode acgt --steps 5 --warmup 1 --cpu-refs 512 > $O/bench_acgt_c2.json 2> $O/bench_acgt_c2.err || exit 1
+step c3;             timeout -k 10 500 python bench.py --mode acgt --queries 10000 --refs 1000000 --steps 1 --warmup 1 --cpu-refs 0 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
+python tools/pmc_summary.py config1_fetch=$(ls $O/pmc_fetch/*counter_collection.csv) config1_write=$(ls $O/pmc_write/*counter_collection.csv) q4_1Mrefs_fetch=$(ls $O/pmc_fetch_q4/*counter_collection.csv) > $O/pmc_traffic.json
+echo done

@@ -618,7 +618,8 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 //     group costs a single ds_add of the reference's own per-group counts (grp[]).
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
 // stream (dwords), per query tile, sdir[qtile] = {first dword, number of group records}:
-//   record = { w4 | needE << 16 | needV << 17,  n_full,  n_generic,  0 }  + n_full LDS offsets (padded to a multiple of 4)
+//   record = { w4 * 2048 (byte offset of the group's E plane in the tile) | needE | needV << 1,  n_full4 = ceil(n_full / 4),  n_generic,
+//              w4 * 256 (byte offset of the group's grp[] row) }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
 //            + n_generic x { ~qI & constMask [4],  ~qV (default) / ~qI (--acgt) [4],  LDS offset, 0, 0, 0 }
 // qpl[q][p4][L,H,I,-][4]: compressed planes of the polymorphic columns
 template <int QT, bool ACGT>
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                      int *__restrict__ mp_out, int parts)
 {
   static_assert(QT == 16, "stream offsets are laid out for tiles of 16 queries");
-  __shared__ uint32_t lacc[4][QT][64];                         // per wave: one packed counter per (query, lane)
+  __shared__ uint32_t lacc[4][QT + 1][64];                     // per wave: one packed counter per (query, lane) + a scratch row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int qtile, group;
   if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
@@ -699,40 +700,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (uint32_t rec = 0; rec < dir.y; rec++) {
       QWords<4> h;
       load_qwords(h, sp);
-      const uint32_t h0 = h.v[0], n_full = h.v[1], n_gen = h.v[2];
-      const uint32_t w4 = h0 & 0xFFFFu;
+      const uint32_t h0 = h.v[0], n_full4 = h.v[1], n_gen = h.v[2];
       sp += 4;
+      const char *tg = reinterpret_cast<const char *>(t) + (h0 & ~1023u);            // E plane of the group, V plane 1 KiB further
       uint4 pE = make_uint4(0, 0, 0, 0), pV = pE;
-      if (h0 & 0x10000u) pE = t[(size_t)(w4 * 2 + 0) * 64];
-      if (h0 & 0x20000u) pV = t[(size_t)(w4 * 2 + 1) * 64];
-      if (n_full) {     // all-N queries: what they take away is the reference's own count for the group (same packing as the counters)
-        const uint32_t g = gt[(size_t)w4 * 64];
-        for (uint32_t k = 0; k < n_full; k++) LDS_ADD(sp[k], g);
-        sp += (n_full + 3u) & ~3u;
+      if (h0 & 1u) pE = *reinterpret_cast<const uint4 *>(tg);
+      if (h0 & 2u) pV = *reinterpret_cast<const uint4 *>(tg + 1024);
+      if (n_full4) {    // all-N queries: what they take away is the reference's own count for the group (same packing as the counters)
+        const uint32_t g = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + h.v[3]);
+#pragma unroll 1
+        for (uint32_t k = 0; k < n_full4; k++, sp += 4) {      // four LDS offsets per step; the list is padded with a scratch row
+          QWords<4> o;
+          load_qwords(o, sp);
+          LDS_ADD(o.v[0], g); LDS_ADD(o.v[1], g); LDS_ADD(o.v[2], g); LDS_ADD(o.v[3], g);
+        }
       }
       if (n_gen) {
         const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
         // two items in flight: the words of the next one arrive while the current one is counted.  TOUCH_ITEM pins the wait for
         // a prefetched item BEFORE the following prefetch is issued (scalar loads return out of order: the only wait is "all").
+        const cst_u32 *ip = sp;
+        sp += n_gen * 12u;
         QWords<9> a, b;
-        load_qwords(a, sp);
+        load_qwords(a, ip);
         TOUCH_ITEM(a);
-        for (uint32_t k = 0; k < n_gen; k += 2) {
-          load_qwords(b, sp + 12);       // the stream is padded: reading past the last item is harmless
+        for (uint32_t k = 0; k < n_gen; k += 2, ip += 24) {
+          load_qwords(b, ip + 12);       // the stream is padded: reading past the last item is harmless
           __builtin_amdgcn_sched_barrier(0);
           COUNT_ITEM(a);
           __builtin_amdgcn_sched_barrier(0);
           TOUCH_ITEM(b);
           if (k + 1 < n_gen) {
-            load_qwords(a, sp + 24);
+            load_qwords(a, ip + 24);
             __builtin_amdgcn_sched_barrier(0);
             COUNT_ITEM(b);
             __builtin_amdgcn_sched_barrier(0);
             TOUCH_ITEM(a);
           }
-          sp += 24;
         }
-        if (n_gen & 1u) sp -= 12;
       }
     }
 #undef LDS_ADD
@@ -1157,19 +1162,29 @@ static __device__ __forceinline__ void iupac_planes_extra(uint32_t rA, uint32_t 
 
 // Single round trip: the reference's side row (count, listed words and their planes) is one coalesced 256-B load, the
 // reference planes at the query's listed words are requested at the same time (they do not depend on the row), and the
-// query's planes come from `qw` (LDS copy of its row when it fits, else global memory).
-static __device__ int2 wave_iupac_extra(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *qw,
-                                        const int *__restrict__ ref_row, int aqv /*lane l < AMB_STRIDE holds the query's list*/, int lane, bool &dense)
+// query's planes come from `qw` (LDS copy of its row when it fits, else global memory).  The request is split from its use
+// so that the replay can have the rows of the next candidates in flight while it works on the heap.
+struct ExtraReq { int row; uint32_t gA, gC, gG, gT; int nn; };
+
+static __device__ __forceinline__ ExtraReq wave_iupac_request(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const int *__restrict__ ref_row,
+                                                              int nq, int wq, int lane)
 {
   const uint32_t *dbw = reinterpret_cast<const uint32_t *>(db);
-  const int nq = __shfl(aqv, 0);
-  const int row = ref_row[lane];
-  const int wq = __shfl(aqv, 1 + ((lane < nq && lane < AMB_CAP) ? lane : 0));
-  uint32_t gA = 0, gC = 0, gG = 0, gT = 0;
+  ExtraReq e;
+  e.row = ref_row[lane];
+  e.gA = e.gC = e.gG = e.gT = 0u; e.nn = 0;
   if (lane < nq && nq <= AMB_CAP) {
     const size_t base = (((size_t)tile_abs * W4 + (wq >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (wq & 3);
-    gA = dbw[base]; gC = dbw[base + 256]; gG = dbw[base + 512]; gT = dbw[base + 768];
+    e.gA = dbw[base]; e.gC = dbw[base + 256]; e.gG = dbw[base + 512]; e.gT = dbw[base + 768];
   }
+  return e;
+}
+
+static __device__ int2 wave_iupac_finish(const ExtraReq &e, const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *qw,
+                                         int aqv /*lane l < AMB_STRIDE holds the query's list*/, int nq, int wq, int lane, bool &dense)
+{
+  const uint32_t *dbw = reinterpret_cast<const uint32_t *>(db);
+  const int row = e.row;
   const int nr = __shfl(row, 0);
   int d1 = 0, d2 = 0;
   dense = (nr > AMB_CAP || nq > AMB_CAP);
@@ -1183,7 +1198,7 @@ static __device__ int2 wave_iupac_extra(const uint4 *__restrict__ db, size_t til
     for (int k = 0; k < nq; k++) dup |= (__shfl(aqv, 1 + k) == wr);
     int w = -1;
     uint32_t rA = 0, rC = 0, rG = 0, rT = 0;
-    if (lane < nq) { w = wq; rA = gA; rC = gC; rG = gG; rT = gT; }
+    if (lane < nq) { w = wq; rA = e.gA; rC = e.gC; rG = e.gG; rT = e.gT; }
     else if (lane < nq + nr && !dup) { w = wr; rA = sA; rC = sC; rG = sG; rT = sT; }
     if (w >= 0) {
       const uint32_t *sq = qw + (size_t)w * 6;
@@ -1257,6 +1272,8 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
     qw = lq;
   }
   const int aqv = (lane < AMB_STRIDE) ? amb_q[(size_t)q * AMB_STRIDE + lane] : 0;      // the query's ambiguity-word list, one int per lane
+  const int aq_n = __shfl(aqv, 0);                                                      // how many words it lists
+  const int aq_w = __shfl(aqv, 1 + ((lane < aq_n && lane < AMB_CAP) ? lane : 0));       // lane l: the l-th listed word
   __syncthreads();
   bool dirty = false;
   unsigned n_admit = 0, n_demand = 0, n_dense = 0;
@@ -1329,23 +1346,69 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
           return K0[u] >= W[0];
         };
         unsigned long long mask = __ballot(may_enter());
+        // What a candidate needs beyond the two scan counters (side row / dist_unique, valid sites of the reference) is requested
+        // for the next PF candidates of the tile while the current one goes through the heap: the requests depend on the
+        // reference only, never on the heap state, so a candidate that drops out after an admission merely wastes its request.
+        constexpr int PF = 3;
+        int pf_idx[PF]; ExtraReq pf[PF];
+#pragma unroll
+        for (int s_ = 0; s_ < PF; s_++) pf_idx[s_] = -1;
+        auto request = [&](int i_) -> ExtraReq {
+          const int rl_ = base_u + i_;
+          ExtraReq e;
+          if (ACGT) { e.row = mpbuf ? mpbuf[(size_t)q * ppad + rl_] : 0; e.gA = e.gC = e.gG = e.gT = 0u; }
+          else e = wave_iupac_request(db, (size_t)tile_first + (size_t)(rl_ >> 6), rl_ & 63, W4, amb + (size_t)rl_ * AMB_ROW, aq_n, aq_w, lane);
+          e.nn = (CONS || ACGT) ? 0 : nonn[rl_];
+          return e;
+        };
         while (mask) {
           const int i = __ffsll((long long)mask) - 1;
+          {   // keep the first PF candidates of the mask requested
+            unsigned long long rest = mask;
+#pragma unroll
+            for (int d_ = 0; d_ < PF; d_++) {
+              if (!rest) break;
+              const int ib = __ffsll((long long)rest) - 1; rest &= rest - 1;
+              bool have = false;
+#pragma unroll
+              for (int s_ = 0; s_ < PF; s_++) have |= (pf_idx[s_] == ib);
+              if (!have) {
+                // free slot: one whose candidate is no longer among the first PF of the mask (or empty)
+                // (the tolerance can rise after an admission, so the mask can gain candidates ahead of the ones already requested:
+                // with no stale slot, the slot of the farthest candidate is given up)
+                int slot = -1, far = 0;
+#pragma unroll
+                for (int s_ = PF - 1; s_ >= 0; s_--) {
+                  if (pf_idx[s_] < 0 || pf_idx[s_] < i || !((mask >> pf_idx[s_]) & 1ull)) slot = s_;
+                  if (pf_idx[s_] > pf_idx[far]) far = s_;
+                }
+                if (slot < 0) slot = far;
+                const ExtraReq e = request(ib);
+#pragma unroll
+                for (int s_ = 0; s_ < PF; s_++) if (s_ == slot) { pf[s_] = e; pf_idx[s_] = ib; }
+              }
+            }
+          }
+          ExtraReq cur = pf[0];
+#pragma unroll
+          for (int s_ = 1; s_ < PF; s_++) if (pf_idx[s_] == i) cur = pf[s_];
+#pragma unroll
+          for (int s_ = 0; s_ < PF; s_++) if (pf_idx[s_] == i) pf_idx[s_] = -1;
           const int rl = base_u + i;                                      // index relative to the first tile of the batch
           const int cx = __shfl(c[u].x, i), cy = __shfl(c[u].y, i);
           const int4 ai = make_int4(__shfl(a[u].x, i), __shfl(a[u].y, i), __shfl(a[u].z, i), __shfl(a[u].w, i));
           const int4 ri = make_int4(__shfl(rc[u].x, i), __shfl(rc[u].y, i), __shfl(rc[u].z, i), __shfl(rc[u].w, i));
-          const int nni = (CONS || ACGT) ? __shfl(nn[u], i) : nonn[rl];
+          const int nni = (CONS || ACGT) ? __shfl(nn[u], i) : cur.nn;
           const size_t tile_abs = (size_t)tile_first + (size_t)(rl >> 6);
           int Si[6], mi;
           n_demand++;
           if (ACGT) {
             // with the column-compressed scan the dense count on the polymorphic columns IS score[5] (src/nearest.c:469)
-            const int mp = mpbuf ? mpbuf[(size_t)q * ppad + rl] : wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
+            const int mp = mpbuf ? cur.row : wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
             assemble_scores<true>(make_int4(cx, cy, mp, 0), ai, ri, nni, Si, mi);
           } else {
             bool dense;
-            const int2 d = wave_iupac_extra(db, tile_abs, rl & 63, W4, qw, amb + (size_t)rl * AMB_ROW, aqv, lane, dense);
+            const int2 d = wave_iupac_finish(cur, db, tile_abs, rl & 63, W4, qw, aqv, aq_n, aq_w, lane, dense);
             n_dense += dense;
             assemble_scores<false>(make_int4(cx, cx + d.x, cx + d.x + d.y, cy), ai, ri, nni, Si, mi);
           }
@@ -1835,10 +1898,10 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
           if ((fx | fy) == 0u) continue;
           const uint32_t fa = (fx | (fx >> 16)) & 0xFFFFu;
-          strm.push_back((uint32_t)g | ((fx & 0xFFFFu) ? 0x10000u : 0u) | ((fx >> 16) ? 0x20000u : 0u));
-          strm.push_back((uint32_t)__builtin_popcount(fy)); strm.push_back((uint32_t)__builtin_popcount(fa)); strm.push_back(0u);
+          strm.push_back((uint32_t)g * 2048u | ((fx & 0xFFFFu) ? 1u : 0u) | ((fx >> 16) ? 2u : 0u));
+          strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u); strm.push_back((uint32_t)__builtin_popcount(fa)); strm.push_back((uint32_t)g * 256u);
           for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * 256u);
-          while (strm.size() & 3) strm.push_back(0u);
+          while (strm.size() & 3) strm.push_back(16u * 256u);                                  // scratch row
           for (uint32_t m = fa; m; m &= m - 1) {
             const int q = __builtin_ctz(m);
             const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;

@@ -1113,6 +1113,46 @@ static __device__ void wave_sift_down(int *h, int n, int p, int lane)
   }
 }
 
+// Root replacement for a full heap: the same comparisons and the same final layout as "overwrite slot 1, sift down"
+// (src/min_heap.c:93-133), but the incoming entry stays in registers (`ment`: lanes l and l+8 hold its int l, l < 8) while
+// the children on its way move up: per level one 64-byte LDS read (both children side by side in lanes 0-15), two
+// lexicographic compares done with ballots and a DPP row shift, one 32-byte write.  No barrier inside: one wave, LDS
+// operations of a wave complete in order.
+static __device__ void wave_replace_root(int *h, int n, int ment, int lane)
+{
+  int p = 1;
+  for (;;) {
+    const int c = 2 * p;
+    if (c > n) break;
+    int v = 0;
+    if (lane < 16 && c + (lane >> 3) <= n) v = h[c * HEAP_ENTRY + lane];               // lanes 0-7: child c, lanes 8-15: child c + 1
+    const unsigned long long ne1 = __ballot(lane < 6 && ment != v), gt1 = __ballot(lane < 6 && ment > v);
+    const bool b1 = ne1 && ((gt1 >> (__ffsll((long long)ne1) - 1)) & 1ull);             // the entry ranks strictly ahead of child c
+    const int c1up = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);         // row_shr:8 -> lanes 8-15 see child c
+    const int pk = b1 ? c1up : ment;                                                    // lanes 8-13: keys of the pick so far
+    const unsigned long long ne2 = __ballot(lane >= 8 && lane < 14 && pk != v), gt2 = __ballot(lane >= 8 && lane < 14 && pk > v);
+    const bool b2 = (c + 1 <= n) && ne2 && ((gt2 >> (__ffsll((long long)ne2) - 1)) & 1ull);   // ... strictly ahead of child c + 1
+    if (!b1 && !b2) break;
+    const int c2dn = __builtin_amdgcn_update_dpp(0, v, 0x108, 0xF, 0xF, false);         // row_shl:8 -> lanes 0-7 see child c + 1
+    if (lane < HEAP_ENTRY) h[p * HEAP_ENTRY + lane] = b2 ? c2dn : v;
+    p = b2 ? c + 1 : c;
+  }
+  if (lane < HEAP_ENTRY) h[p * HEAP_ENTRY + lane] = ment;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// sum over the wave by DPP (row shifts, then row broadcasts): six VALU steps instead of six LDS-crossbar shuffles
+static __device__ __forceinline__ int wave_sum_dpp(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);    // row_shr:8  -> lane 15 of every row holds the row's sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 static __device__ void wave_sift_up(int *h, int i, int lane)
 { // src/min_heap.c:135-147
   while (i > 1) {
@@ -1164,52 +1204,54 @@ static __device__ __forceinline__ void iupac_planes_extra(uint32_t rA, uint32_t 
 // reference planes at the query's listed words are requested at the same time (they do not depend on the row), and the
 // query's planes come from `qw` (LDS copy of its row when it fits, else global memory).  The request is split from its use
 // so that the replay can have the rows of the next candidates in flight while it works on the heap.
-struct ExtraReq { int row; uint32_t gA, gC, gG, gT; int nn; };
+// Roles by lane: lanes 0..nq-1 take the query's listed words (reference planes gathered from the database tile), lanes
+// nq..nq+AMB_CAP-1 the reference's listed words (index and planes straight from its side row), every lane the row's count.
+struct ExtraReq { int row /* --acgt: dist_unique; default: the reference's count */; int w; uint32_t rA, rC, rG, rT; int nn; };
 
 static __device__ __forceinline__ ExtraReq wave_iupac_request(const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const int *__restrict__ ref_row,
                                                               int nq, int wq, int lane)
 {
   const uint32_t *dbw = reinterpret_cast<const uint32_t *>(db);
   ExtraReq e;
-  e.row = ref_row[lane];
-  e.gA = e.gC = e.gG = e.gT = 0u; e.nn = 0;
-  if (lane < nq && nq <= AMB_CAP) {
-    const size_t base = (((size_t)tile_abs * W4 + (wq >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (wq & 3);
-    e.gA = dbw[base]; e.gC = dbw[base + 256]; e.gG = dbw[base + 512]; e.gT = dbw[base + 768];
+  e.row = ref_row[0];
+  e.w = -1; e.rA = e.rC = e.rG = e.rT = 0u; e.nn = 0;
+  if (nq <= AMB_CAP) {
+    if (lane < nq) {
+      const size_t base = (((size_t)tile_abs * W4 + (wq >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (wq & 3);
+      e.w = wq; e.rA = dbw[base]; e.rC = dbw[base + 256]; e.rG = dbw[base + 512]; e.rT = dbw[base + 768];
+    } else if (lane < nq + AMB_CAP) {
+      const int kr = lane - nq;
+      const int4 pl = *reinterpret_cast<const int4 *>(ref_row + 12 + 4 * kr);
+      e.w = ref_row[1 + kr]; e.rA = (uint32_t)pl.x; e.rC = (uint32_t)pl.y; e.rG = (uint32_t)pl.z; e.rT = (uint32_t)pl.w;
+    }
   }
   return e;
 }
 
 static __device__ int2 wave_iupac_finish(const ExtraReq &e, const uint4 *__restrict__ db, size_t tile_abs, int lane_r, int W4, const uint32_t *qw,
-                                         int aqv /*lane l < AMB_STRIDE holds the query's list*/, int nq, int wq, int lane, bool &dense)
+                                         const uint32_t *qlisted /*LDS bitmap of the words the query lists*/, int nq, int lane, bool &dense)
 {
   const uint32_t *dbw = reinterpret_cast<const uint32_t *>(db);
-  const int row = e.row;
-  const int nr = __shfl(row, 0);
-  int d1 = 0, d2 = 0;
+  const int nr = e.row;
   dense = (nr > AMB_CAP || nq > AMB_CAP);
   if (!dense) {
-    // lanes 0..nq-1: the query's words;  lanes nq..nq+nr-1: the reference's words the query does not list itself
-    const int kr = (lane >= nq && lane < nq + nr) ? lane - nq : 0;
-    const int wr = __shfl(row, 1 + kr);
-    const uint32_t sA = (uint32_t)__shfl(row, 12 + 4 * kr + 0), sC = (uint32_t)__shfl(row, 12 + 4 * kr + 1),
-                   sG = (uint32_t)__shfl(row, 12 + 4 * kr + 2), sT = (uint32_t)__shfl(row, 12 + 4 * kr + 3);
-    bool dup = false;
-    for (int k = 0; k < nq; k++) dup |= (__shfl(aqv, 1 + k) == wr);
-    int w = -1;
-    uint32_t rA = 0, rC = 0, rG = 0, rT = 0;
-    if (lane < nq) { w = wq; rA = e.gA; rC = e.gC; rG = e.gG; rT = e.gT; }
-    else if (lane < nq + nr && !dup) { w = wr; rA = sA; rC = sC; rG = sG; rT = sT; }
-    if (w >= 0) {
-      const uint32_t *sq = qw + (size_t)w * 6;
-      iupac_planes_extra(rA, rC, rG, rT, sq[0], sq[1], sq[2], sq[3], sq[5], d1, d2);
+    int pk = 0;
+    // the reference's words the query lists itself are already covered by the query's lanes
+    const bool mine = lane < nq || (lane < nq + nr && !((qlisted[e.w >> 5] >> (e.w & 31)) & 1u));
+    if (mine) {
+      const uint32_t *sq = qw + (size_t)e.w * 6;
+      int d1 = 0, d2 = 0;
+      iupac_planes_extra(e.rA, e.rC, e.rG, e.rT, sq[0], sq[1], sq[2], sq[3], sq[5], d1, d2);
+      pk = d1 | (d2 << 16);                                   // at most 64 x 32 per half
     }
-  } else {
-    for (int w = lane; w < W4 * 4; w += 64) {
-      const size_t base = (((size_t)tile_abs * W4 + (w >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (w & 3);
-      const uint32_t *sq = qw + (size_t)w * 6;
-      iupac_planes_extra(dbw[base], dbw[base + 256], dbw[base + 512], dbw[base + 768], sq[0], sq[1], sq[2], sq[3], sq[5], d1, d2);
-    }
+    const int tot = wave_sum_dpp(pk);
+    return make_int2(tot & 0xFFFF, (int)((unsigned)tot >> 16));
+  }
+  int d1 = 0, d2 = 0;
+  for (int w = lane; w < W4 * 4; w += 64) {
+    const size_t base = (((size_t)tile_abs * W4 + (w >> 2)) * 4) * 256 + (size_t)lane_r * 4 + (w & 3);
+    const uint32_t *sq = qw + (size_t)w * 6;
+    iupac_planes_extra(dbw[base], dbw[base + 256], dbw[base + 512], dbw[base + 768], sq[0], sq[1], sq[2], sq[3], sq[5], d1, d2);
   }
   return make_int2(wave_sum(d1), wave_sum(d2));
 }
@@ -1274,6 +1316,10 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   const int aqv = (lane < AMB_STRIDE) ? amb_q[(size_t)q * AMB_STRIDE + lane] : 0;      // the query's ambiguity-word list, one int per lane
   const int aq_n = __shfl(aqv, 0);                                                      // how many words it lists
   const int aq_w = __shfl(aqv, 1 + ((lane < aq_n && lane < AMB_CAP) ? lane : 0));       // lane l: the l-th listed word
+  uint32_t *qlisted = reinterpret_cast<uint32_t *>(h + (k + 1) * HEAP_ENTRY) + lq_words;   // 32-word bitmap of the listed words
+  if (lane < 32) qlisted[lane] = 0u;
+  __syncthreads();
+  if (lane < aq_n && aq_n <= AMB_CAP) atomicOr(&qlisted[aq_w >> 5], 1u << (aq_w & 31));
   __syncthreads();
   bool dirty = false;
   unsigned n_admit = 0, n_demand = 0, n_dense = 0;
@@ -1356,7 +1402,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
         auto request = [&](int i_) -> ExtraReq {
           const int rl_ = base_u + i_;
           ExtraReq e;
-          if (ACGT) { e.row = mpbuf ? mpbuf[(size_t)q * ppad + rl_] : 0; e.gA = e.gC = e.gG = e.gT = 0u; }
+          if (ACGT) { e.row = mpbuf ? mpbuf[(size_t)q * ppad + rl_] : 0; e.w = -1; e.rA = e.rC = e.rG = e.rT = 0u; }
           else e = wave_iupac_request(db, (size_t)tile_first + (size_t)(rl_ >> 6), rl_ & 63, W4, amb + (size_t)rl_ * AMB_ROW, aq_n, aq_w, lane);
           e.nn = (CONS || ACGT) ? 0 : nonn[rl_];
           return e;
@@ -1408,7 +1454,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
             assemble_scores<true>(make_int4(cx, cy, mp, 0), ai, ri, nni, Si, mi);
           } else {
             bool dense;
-            const int2 d = wave_iupac_finish(cur, db, tile_abs, rl & 63, W4, qw, aqv, aq_n, aq_w, lane, dense);
+            const int2 d = wave_iupac_finish(cur, db, tile_abs, rl & 63, W4, qw, qlisted, aq_n, lane, dense);
             n_dense += dense;
             assemble_scores<false>(make_int4(cx, cx + d.x, cx + d.x + d.y, cy), ai, ri, nni, Si, mi);
           }
@@ -1416,17 +1462,17 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
           if (!accept) { mask &= mask - 1; continue; }
           {
             const long long ord = ord_base + (rl - r_begin);
-            const int slot = full ? 1 : n + 1;
-            if (lane < HEAP_ENTRY) {
-              int v = (int)(unsigned)(ord & 0xffffffffll);
-              if (lane == 7) v = (int)(ord >> 32);
+            int v = (int)(unsigned)(ord & 0xffffffffll);                   // lanes l and l + 8 hold int l of the new entry
+            if ((lane & 7) == 7) v = (int)(ord >> 32);
 #pragma unroll
-              for (int sidx = 0; sidx < 6; sidx++) if (lane == sidx) v = Si[sidx];
-              h[slot * HEAP_ENTRY + lane] = v;
-            }
+            for (int sidx = 0; sidx < 6; sidx++) if ((lane & 7) == sidx) v = Si[sidx];
             if (lane == 0) entered[rl] = 1;
-            __syncthreads();
-            if (full) wave_sift_down(h, n, 1, lane); else wave_sift_up(h, n + 1, lane);
+            if (full) wave_replace_root(h, n, v, lane);
+            else {
+              if (lane < HEAP_ENTRY) h[(n + 1) * HEAP_ENTRY + lane] = v;
+              __syncthreads();
+              wave_sift_up(h, n + 1, lane);
+            }
           }
           if (!full) n++;
           dirty = true; n_admit++;
@@ -1649,7 +1695,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   HIPCHK(c, hipGetLastError());
   const double bytes = (double)(r_end - r_begin) * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
   size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
-  const int lq_words = (!c->acgt && !c->fullscan && lds + (size_t)c->W4 * 4 * 6 * 4 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;   // query planes cached in LDS
+  const int lq_words = (!c->acgt && !c->fullscan && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;   // query planes cached in LDS
   if (c->fullscan) {
     int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
     rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq, c->d_cnt, ppad, bytes);
@@ -1659,7 +1705,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   } else {
     int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0]);
     if (rc) return rc;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
                                     c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int *)nullptr, \
                                     c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
@@ -1775,7 +1821,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
   c->max_pool = max_pool; c->pool_pad = ((max_pool + 63) / 64) * 64 + 64;
   c->pitch = ((size_t)c->nchar + 63) / 64 * 64;
-  if ((size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) > 160 * 1024) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "nbest=%d does not fit the per-query LDS heap (max 5119)", heap_size); }
+  if ((size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) + 128 > 160 * 1024) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "nbest=%d does not fit the per-query LDS heap (max 5115)", heap_size); }
 
 #define OPENCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int code_ = fail(nullptr, e_ == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); uvaia_gpu_close(c); return code_; } } while (0)
   {  // the gate/replay stream outranks the scan stream: its few waves sit on the critical path of the state chain
@@ -1961,7 +2007,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_stage, (size_t)PACK_CHUNK * c->pitch));
   OPENCHK(hipHostMalloc(&c->h_stage, (size_t)PACK_CHUNK * c->pitch, hipHostMallocDefault));
   memset(c->h_stage, 'N', (size_t)PACK_CHUNK * c->pitch);
-  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) + 128;      // heap + the listed-words bitmap of replay2_kernel
   if (lds > 64 * 1024) {
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2116,7 +2162,11 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
     const size_t sub = (c->nq >= (env_minq ? atoi(env_minq) : 256)) ? c->subslice : pool;
     for (size_t a = 0; a < c->db_n; a += pool) {
       const size_t pe = std::min(c->db_n, a + pool);
-      for (size_t x = a; x < pe; x += sub) subs.push_back({x, std::min(sub, pe - x), x == a});
+      // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
+      // one launch, not a full one plus a sliver whose launch latency and replay would sit on the critical path
+      const size_t len = pe - a, ns = std::max<size_t>(1, (len + sub / 2) / sub);
+      const size_t each = ((len + ns - 1) / ns + 63) / 64 * 64;
+      for (size_t x = a; x < pe; x += each) subs.push_back({x, std::min(each, pe - x), x == a});
     }
     const size_t ns = subs.size();
     size_t issued = 0;
@@ -2287,11 +2337,11 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
     c->slice_cons_done[buf] = true;
   }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
-  const int lq_words = (!c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
+  const int lq_words = (!c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
   const int2 *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int *)nullptr, \
                                   c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }

@@ -159,7 +159,8 @@ def main():
         "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
         "algorithmic_bytes_per_launch": scan_bytes / launches,
         "dense_equivalent_tlaneops_per_s": round(valu_rate, 2),
-        "note": "at %d resident queries the scan is integer-VALU bound, not HBM bound (DESIGN.md)" % pq.ntax,
+        "note": ("at %d resident queries every reference byte is reused by every query tile: the scan is bound by instruction issue "
+                 "(VALU popcounts + scalar bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (profiles/r01_sweep_q*.json, DESIGN.md 4.1)") % pq.ntax,
     }
 
     # HBM-side traffic of the scan from the committed PMC passes (rocprofv3 cannot run inside this process); only quoted
@@ -170,6 +171,14 @@ def main():
         if same and not fullscan and world == 1 and os.environ.get("UVAIA_GPU_SCAN", "") == pm.get("variant", ""):
             roofline["traffic"] = pm["hbm_side_read_bytes_per_launch"] + pm["write_bytes_per_launch"]
             roofline["traffic_note"] = "FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch, profiles/r01_pmc_traffic.json; L2 misses incl. Infinity-Cache hits"
+            if pm.get("wave_instructions_all_dispatches") and pm.get("instruction_mix_all_dispatches", {}).get("SQ_WAVES"):
+                # instruction issue: wave-instructions per (16 queries x 64 references) wave from the committed SQ passes, times the
+                # waves of the timed region, over the measured scan time; peak = tools/issue_rate.hip (VALU + SALU mixed, whole chip)
+                per_wave = pm["wave_instructions_all_dispatches"] / pm["instruction_mix_all_dispatches"]["SQ_WAVES"]
+                waves = ((pq.ntax + 15) // 16) * ((args.refs + 63) // 64) * args.steps
+                rate = per_wave * waves / (scan_ms * 1e-3) / 1e9
+                roofline["issue"] = {"wave_instructions_per_wave": round(per_wave), "achieved": round(rate, 1), "peak": 1037.0, "unit": "G wave-instr/s",
+                                     "frac": round(rate / 1037.0, 3), "source": "profiles/r01_pmc_traffic.json, profiles/r01_issue_rate_microbench.txt"}
     except Exception:
         pass
 
@@ -209,7 +218,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "multi_gpu": None if world == 1 else "block-cyclic slices of %d refs, concurrent scans, heap state (%d B in %d per-query-group blobs) pipelined rank to rank (RCCL isend/irecv), exact" % (pool, nbytes, world),
             "dtype": "u32 bit-planes / int32 counts", "data": "synthetic (seed %d, preset %d)" % (args.seed, args.preset),
-            "config": {"workload": "BASELINE config[1]: %d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d"
+            "config": {"workload": (("BASELINE config[1]: " if (pq.ntax, args.refs, args.nchar, args.nbest) == (1000, 100000, 29903, 100) else
+                                     "BASELINE config[2]: " if (pq.ntax, args.refs, args.nchar, args.nbest, args.mode) == (10000, 1000000, 29903, 100, "acgt") else "")
+                                    + "%d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d")
                                    % (pq.ntax, args.refs, args.nchar, "4-bit IUPAC planes" if args.mode == "iupac" else "2-bit + validity planes (--acgt)", args.nbest, pool),
                        "queries": pq.ntax, "refs_per_gpu": args.refs, "nchar": args.nchar, "nbest": args.nbest, "pool": pool,
                        "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2)},

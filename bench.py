@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=20241008)
     ap.add_argument("--qt", type=int, default=0, help="query tile of the scan kernel (8/16/32, 0 = default)")
     ap.add_argument("--cpu-refs", type=int, default=1536, help="references in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-refs-1thread", type=int, default=48, help="sample of the single-thread CPU baseline")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
     return ap.parse_args()
 
@@ -135,29 +136,33 @@ def main():
     # ---- roofline of the dominant kernel (pair scan): algorithmic bytes per launch / mean launch time (HIP events)
     launches = max(1, scan_launches)
     avg_ms = scan_ms / launches
-    achieved = (scan_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     W = (args.nchar + 31) // 32
     fullscan = os.environ.get("UVAIA_GPU_FULLSCAN", "0") not in ("", "0")
     ops_per_pair_word = (15 if args.mode == "iupac" else 8) if fullscan else 6
     valu_ops = float(args.refs) * pq.ntax * W * ops_per_pair_word * args.steps       # lane-ops in the timed region
     valu_rate = valu_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     # The column-compressed scan does not read the 4-bit records themselves but planes derived from them for this query set
-    # (E and V planes + the gathered polymorphic columns): fewer bytes per reference than the packed record.  `achieved` uses the
-    # bytes this kernel has to read; the rate on the nominal packed size of SURVEY 8d is reported next to it.
+    # (E and V planes + the gathered polymorphic columns): fewer bytes per reference than the packed record.
     if fullscan or os.environ.get("UVAIA_GPU_SCAN", "") in ("sgpr", "lds"):
         kernel_bytes_per_ref = bytes_per_ref
     else:
         kernel_bytes_per_ref = eng.scan_bytes_per_ref()
-    nominal = achieved
-    achieved = achieved * kernel_bytes_per_ref / bytes_per_ref
+    # `achieved` is SURVEY 8d's implementation-independent figure: ceil(L*b/8) bytes per reference (14 952 at 4 bits, 11 214 with
+    # 2 bits + validity plane), each reference byte once per launch.  The bytes THIS kernel has to read (derived planes, only the
+    # word groups some query tile needs) are fewer; the rate on those is given next to it and is the one PMC FETCH_SIZE verifies.
+    survey_bytes_per_ref = (args.nchar * 4 + 7) // 8 if args.mode == "iupac" else (args.nchar * 2 + 7) // 8 + (args.nchar + 7) // 8
+    refs_per_launch = float(args.refs) * args.steps / launches
+    achieved = refs_per_launch * survey_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    on_kernel_bytes = refs_per_launch * kernel_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "kernel_bytes_per_ref": kernel_bytes_per_ref, "achieved_on_nominal_packed_size": round(nominal, 2),
+        "algorithmic_bytes_per_ref": survey_bytes_per_ref, "kernel_bytes_per_ref": kernel_bytes_per_ref,
+        "achieved_on_kernel_bytes": round(on_kernel_bytes, 2), "frac_on_kernel_bytes": round(on_kernel_bytes / HBM_PEAK_GBS, 5),
         "kernel": ("scan_%s_kernel" % args.mode) if fullscan else {"lds": "scan2v_kernel", "sgpr": "scan2_%s_kernel" % args.mode}.get(os.environ.get("UVAIA_GPU_SCAN", ""), "scan3_kernel"),
         "dense_equivalent_ops_per_pair_word": ops_per_pair_word,
         "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
-        "algorithmic_bytes_per_launch": scan_bytes / launches,
+        "algorithmic_bytes_per_launch": refs_per_launch * survey_bytes_per_ref,
         "dense_equivalent_tlaneops_per_s": round(valu_rate, 2),
         "note": ("at %d resident queries every reference byte is reused by every query tile: the scan is bound by instruction issue "
                  "(VALU popcounts + scalar bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (profiles/r01_sweep_q*.json, DESIGN.md 4.1)") % pq.ntax,
@@ -199,6 +204,23 @@ def main():
         cpu = {"value": round(n_s / cpu_s, 2), "unit": "ref-seqs/s", "cores": cores, "kind": "port",
                "sample": "first %d references of the same database vs the same %d queries, pool %d, OpenMP over %d threads, %.1f s"
                          % (n_s, oq.ntax, min(pool, n_s), cores, cpu_s)}
+        try:        # the same restatement on one thread, on a smaller sample
+            import ctypes
+            gomp = ctypes.CDLL("libgomp.so.1")
+            n_1 = max(1, min(n_s, args.cpu_refs_1thread))
+            gomp.omp_set_num_threads(1)
+            t0 = time.perf_counter()
+            O.search(oq, sample[:n_1], snames[:n_1], pool=min(pool, n_1), nbest=args.nbest, ambig_r=0.5)
+            t1 = time.perf_counter() - t0
+            gomp.omp_set_num_threads(cores)
+            cpu["value_1_thread"] = round(n_1 / t1, 2)
+            cpu["sample_1_thread"] = "first %d references, 1 thread, %.1f s" % (n_1, t1)
+        except OSError:
+            pass
+        try:
+            cpu["host"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
         if not args.no_parity:      # the same sample through the GPU engine must give the same heaps
             eng.reset()
             with pq.open_engine(nbest=args.nbest, max_pool=min(pool, n_s), device=local_rank) as e2:

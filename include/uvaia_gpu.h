@@ -147,6 +147,21 @@ int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, d
 int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int reset);
 /* tuning knob: queries held per pass of the scan kernel (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
+/* ---- packed interchange form (packed on-disk database).  Replaces, for a database that was packed once,
+ * the serial text path of the reference (readfasta_next src/fastaseq.c:422-474 + the slot filling of src/nearest.c:251-286 +
+ * quick_count_sequence_non_N src/fastaseq.c:642-648): tiles of 64 references, each uvaia_gpu_db_tile_bytes() long, laid out
+ * [word group][plane A,C,G,T][lane] as 16-byte words (plane bit s of word w = site 32 w + s carries that IUPAC set bit), the
+ * valid-site counts, and per reference a side row of uvaia_gpu_db_side_row_ints() ints (its partially ambiguous words).  The form
+ * does not depend on the query set or on --acgt (an --acgt context re-codes the planes while importing).
+ *   export:        from a default-mode (4-plane) context whose database was filled by uvaia_gpu_db_append*; arrays hold n_tiles*64
+ *                  entries (lanes past the last reference are zero)
+ *   append_packed: n_ref references = ceil(n_ref/64) tiles; the database must hold a whole number of tiles before the call */
+size_t uvaia_gpu_db_tile_bytes (const uvaia_gpu_ctx *ctx);
+int    uvaia_gpu_db_clear (uvaia_gpu_ctx *ctx);                      /* empties the resident database, keeps its capacity */
+int    uvaia_gpu_db_side_row_ints (void);
+int    uvaia_gpu_db_export (uvaia_gpu_ctx *ctx, size_t first_tile, size_t n_tiles, void *planes, int *non_n, int *side_rows);
+int    uvaia_gpu_db_append_packed (uvaia_gpu_ctx *ctx, const void *planes, const int *non_n, const int *side_rows, int n_ref);
+
 /* bytes the pair scan reads per reference (the default scan reads planes derived from the packed record for this query set) */
 size_t uvaia_gpu_scan_bytes_per_ref (const uvaia_gpu_ctx *ctx);
 /* bytes per packed reference in HBM */

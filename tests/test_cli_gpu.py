@@ -114,3 +114,38 @@ def test_uvaiaball_cli_matches_oracle(files):
     md, keep = q.ball(rseqs[:1200], ambig_r=0.5)
     dump_names, dump_seqs = F.read_fasta_bytes(lzma.open(out + ".aln.xz", "rb").read())
     assert dump_names == [rnames[i] for i in np.nonzero(keep)[0]]
+
+
+UVAIAPACK = os.path.join(ROOT, "bin", "uvaiapack")
+
+
+@pytest.mark.parametrize("extra", [[], ["--acgt"], ["--trim", "230", "-k"]])
+def test_packed_database_gives_the_same_files_as_the_text_path(files, extra):
+    """`uvaiapack` + `uvaia --packed` against `uvaia -r` on the same references (two files, one xz, with gaps,
+    ambiguity codes and sequences the -A filter drops): identical table and identical dump, byte for byte."""
+    d, qn, qs, rnames, rseqs = files
+    db = str(d / "refs.uvdb")
+    if not os.path.exists(db):
+        subprocess.run([UVAIAPACK, "-o", db, str(d / "ref1.aln.xz"), str(d / "ref2.fa")], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600)
+    tag = "_".join(x.strip("-") for x in extra) or "default"
+    out_t, out_p = str(d / ("t_" + tag)), str(d / ("p_" + tag))
+    common = [str(d / "query.fa"), "-p", "200", "-n", "5"] + extra
+    subprocess.run([UVAIA, "-r", str(d / "ref1.aln.xz"), "-r", str(d / "ref2.fa"), "-o", out_t] + common, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    subprocess.run([UVAIA, "--packed", db, "-o", out_p] + common, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    assert _read_xz_text(out_p + ".csv.xz") == _read_xz_text(out_t + ".csv.xz")
+    assert lzma.open(out_p + ".aln.xz", "rb").read() == lzma.open(out_t + ".aln.xz", "rb").read()
+    assert len(_read_xz_text(out_p + ".csv.xz").splitlines()) > 10
+
+
+def test_packed_database_refuses_what_it_cannot_honour(files):
+    d = files[0]
+    db = str(d / "refs.uvdb")
+    if not os.path.exists(db):
+        subprocess.run([UVAIAPACK, "-o", db, str(d / "ref1.aln.xz"), str(d / "ref2.fa")], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600)
+    for bad in (["-A", "0.3"], ["-x"]):
+        r = subprocess.run([UVAIA, "--packed", db, str(d / "query.fa"), "-o", str(d / "refused")] + bad, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode != 0 and b"packed" in r.stderr

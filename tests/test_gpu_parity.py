@@ -132,6 +132,36 @@ def test_resident_equals_streaming(synth):
             assert capi.finalise_heaps(n2, sc2, od2) == rows_s
 
 
+def test_packed_interchange_form_round_trip(synth):
+    """a database exported in packed form (from a default-mode context) and imported again -- into a default
+    and into an --acgt context, in two tile-aligned pieces -- gives the same heaps as the text path."""
+    refs, qs = synth
+    q4 = O.Query(qs, _names(len(qs), "q"))
+    with capi.Engine.from_query(q4, nbest=7, max_pool=512) as eng:
+        eng.db_append(refs)
+        planes, non_n, side = eng.db_export()
+    assert planes.shape[0] == (len(refs) + 63) // 64
+    for acgt in (False, True):
+        q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+        rows_s, T_s, ent_s = _gpu_search(q, refs, 100, 7)
+        with capi.Engine.from_query(q, nbest=7, max_pool=512) as eng:
+            eng.db_reserve(len(refs))
+            eng.db_append_packed(planes[:2], non_n[:128], side[:128], 128)
+            eng.db_append_packed(planes[2:], non_n[128:], side[128:], len(refs) - 128)
+            assert eng.db_size() == len(refs)
+            ent = eng.search_resident(100)
+            n, T, sc, od = eng.drain()
+            assert capi.finalise_heaps(n, sc, od) == rows_s
+            assert list(T) == T_s
+            assert np.array_equal(ent, ent_s)
+            with pytest.raises(capi.GpuError):          # a partial tile cannot be followed by packed tiles
+                eng.db_append_packed(planes[:1], non_n[:64], side[:64], 64)
+    with capi.Engine.from_query(O.Query(qs, _names(len(qs), "q"), acgt=True), nbest=7, max_pool=512) as eng:
+        eng.db_append(refs[:64])
+        with pytest.raises(capi.GpuError):              # the interchange form is exported from a 4-plane context
+            eng.db_export()
+
+
 def test_query_tile_sizes_agree(synth):
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"))

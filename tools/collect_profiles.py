@@ -46,7 +46,8 @@ def main():
             "config": {"queries": bench["config"]["queries"], "refs_per_gpu": bench["config"]["refs_per_gpu"], "pool": bench["config"]["pool"], "mode": bench["config"]["mode"]},
             "variant": "",
             "hbm_side_read_bytes_per_launch": fetch_kb * 1024 * 2, "write_bytes_per_launch": write_kb * 1024,
-            "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] * bench["roofline"]["kernel_bytes_per_ref"] / bench["config"]["packed_bytes_per_ref"],
+            "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+            "kernel_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] * bench["roofline"]["kernel_bytes_per_ref"] / bench["roofline"]["algorithmic_bytes_per_ref"],
         },
         "q4_1Mrefs_one_launch_check": {"fetch_bytes_corrected": q4_kb * 1024 * 2, "kernel_bytes": q4_alg, "ratio": q4_kb * 1024 * 2 / q4_alg},
         "raw": summ,

@@ -19,6 +19,7 @@ SYMBOLS = [
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
     "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
+    "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear",
 ]
 
 
@@ -99,6 +100,11 @@ def load_library():
         "uvaia_gpu_scan_bytes_per_ref": (C.c_size_t, [vp]),
         "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
+        "uvaia_gpu_db_tile_bytes": (C.c_size_t, [vp]),
+        "uvaia_gpu_db_clear": (C.c_int, [vp]),
+        "uvaia_gpu_db_side_row_ints": (C.c_int, []),
+        "uvaia_gpu_db_export": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_void_p, pi, pi]),
+        "uvaia_gpu_db_append_packed": (C.c_int, [vp, C.c_void_p, pi, pi, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -217,6 +223,29 @@ class Engine:
 
     def db_size(self):
         return self.L.uvaia_gpu_db_size(self.ctx)
+
+    def db_clear(self):
+        self._chk(self.L.uvaia_gpu_db_clear(self.ctx))
+
+    def db_export(self, first_tile=0, n_tiles=None):
+        """Packed interchange form of the resident database: (planes uint8 [n_tiles, tile_bytes], non_n int32 [n_tiles*64],
+        side_rows int32 [n_tiles*64, row_ints])."""
+        if n_tiles is None:
+            n_tiles = (self.db_size() + 63) // 64 - first_tile
+        tb, ri = self.L.uvaia_gpu_db_tile_bytes(self.ctx), self.L.uvaia_gpu_db_side_row_ints()
+        planes = np.zeros((n_tiles, tb), dtype=np.uint8)
+        non_n = np.zeros(n_tiles * 64, dtype=np.int32)
+        side = np.zeros((n_tiles * 64, ri), dtype=np.int32)
+        self._chk(self.L.uvaia_gpu_db_export(self.ctx, first_tile, n_tiles, planes.ctypes.data, non_n.ctypes.data_as(C.POINTER(C.c_int)),
+                                             side.ctypes.data_as(C.POINTER(C.c_int))))
+        return planes, non_n, side
+
+    def db_append_packed(self, planes, non_n, side_rows, n_ref):
+        planes = np.ascontiguousarray(planes, dtype=np.uint8)
+        non_n = np.ascontiguousarray(non_n, dtype=np.int32)
+        side_rows = np.ascontiguousarray(side_rows, dtype=np.int32)
+        self._chk(self.L.uvaia_gpu_db_append_packed(self.ctx, planes.ctypes.data, non_n.ctypes.data_as(C.POINTER(C.c_int)),
+                                                    side_rows.ctypes.data_as(C.POINTER(C.c_int)), int(n_ref)))
 
     def search_resident(self, pool, ordinal0=0, want_entered=True):
         ent, p = None, None

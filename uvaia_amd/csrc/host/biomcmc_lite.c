@@ -238,7 +238,7 @@ biomcmc_open_compress (const char *path, const char *mode)
     else fc->fp = fopen (path, "r");
   } else {
     const char *tool = NULL;   /* the reference tries xz, then bz2, then gz, then plain text (src/nearest.c:234) */
-    if (ends_with (path, ".xz") && tool_available ("xz")) tool = "xz -c";
+    if (ends_with (path, ".xz") && tool_available ("xz")) tool = "xz -T0 -c";   /* all cores: the dump of a large search is hundreds of MB of text */
     else if (ends_with (path, ".bz2") && tool_available ("bzip2")) tool = "bzip2 -c";
     else if (ends_with (path, ".gz") && tool_available ("gzip")) tool = "gzip -c";
     if (tool) { sprintf (cmd, "%s > %s", tool, quoted); fc->fp = popen (cmd, "w"); fc->piped = 1; }

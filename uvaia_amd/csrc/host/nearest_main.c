@@ -11,11 +11,12 @@
 #include "cli_common.h"
 #include "gpu_glue.h"
 #include "prepare.h"
+#include "uvdb.h"
 
 typedef struct {
   int help, version, acgt, keep_resolved, exclude_self, nbest, trim, pool, threads, threads_given, device;
   double ambig_q, ambig_r;
-  const char *out, *query;
+  const char *out, *query, *packed;
   const char **ref; int n_ref;
 } options;
 
@@ -37,6 +38,7 @@ usage (const char *prog, int long_help)
   printf ("  -a, --query_ambiguity=<double>   maximum allowed ambiguity for QUERY sequence to be excluded (default=0.5)\n");
   printf ("  -p, --pool=<int>                 Pool size, i.e. how many reference seqs are sent to the GPU per batch (defaults to 64 per host thread; larger is faster)\n");
   printf ("  -r, --reference=<ref.fa(.gz,.xz)> aligned reference sequences (can be several files)\n");
+  printf ("  --packed=<db.uvdb>               reference database packed by `uvaiapack` (instead of -r): loaded as it is, no text parsing\n");
   printf ("  <seqs.fa(.gz,.xz)>               aligned query sequences\n");
   printf ("  -t, --nthreads=<int>             suggested number of host threads (only sets the default pool size here)\n");
   printf ("  -o, --output=<without suffix>    prefix of xzipped output alignment and table with nearest neighbour sequences\n");
@@ -64,7 +66,7 @@ parse_options (int argc, char **argv)
     {"keep_resolved", no_argument, 0, 'k'}, {"exclude_self", no_argument, 0, 'x'}, {"nbest", required_argument, 0, 'n'},
     {"trim", required_argument, 0, 1001}, {"query_ambiguity", required_argument, 0, 'a'}, {"ref_ambiguity", required_argument, 0, 'A'},
     {"pool", required_argument, 0, 'p'}, {"reference", required_argument, 0, 'r'}, {"nthreads", required_argument, 0, 't'},
-    {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1002}, {0, 0, 0, 0}};
+    {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1002}, {"packed", required_argument, 0, 1003}, {0, 0, 0, 0}};
   int ch, errors = 0;
   while ((ch = getopt_long (argc, argv, "hvkxn:a:A:p:r:t:o:", longopts, NULL)) != -1) switch (ch) {
     case 'h': o.help = 1; break;
@@ -81,13 +83,14 @@ parse_options (int argc, char **argv)
     case 't': o.threads = atoi (optarg); o.threads_given = 1; break;
     case 'o': o.out = optarg; break;
     case 1002: o.device = atoi (optarg); break;
+    case 1003: o.packed = optarg; break;
     default: errors++;
   }
   if (optind < argc) o.query = argv[optind++];
   if (optind < argc) errors++;
   if (o.version) { printf ("%s\n", UVAIA_PACKAGE_VERSION); exit (EXIT_SUCCESS); }
   if (o.help) { usage (basename (argv[0]), 1); exit (EXIT_SUCCESS); }
-  if (errors || !o.query || !o.n_ref) {
+  if (errors || !o.query || (!o.n_ref && !o.packed) || (o.n_ref && o.packed)) {
     printf ("Error when reading arguments from command line:\n");
     usage (basename (argv[0]), 0);
     exit (EXIT_FAILURE);
@@ -179,6 +182,36 @@ main (int argc, char **argv)
            query->n_idx + query->n_idx_c + query->n_idx_m, query->aln->nchar);
   fprintf (stderr, "\n The next step is main comparison, which may take a while\n\n");
 
+  if (o.packed) {     /* resident search over a packed database: replaces the read/filter/fill loop below (src/nearest.c:251-286) */
+    char msg[512];
+    uvdb_reader db = uvdb_open (o.packed, msg, sizeof msg);
+    if (!db) biomcmc_error ("%s", msg);
+    if ((int) db->h.nchar != query->aln->nchar) biomcmc_error ("packed database %s has %u sites but query sequences have %d sites; all sequences must be aligned", o.packed, db->h.nchar, query->aln->nchar);
+    if (db->h.ref_ambiguity != o.ambig_r) biomcmc_error ("packed database %s was filtered with -A %g: use the same value (its filter cannot be undone or tightened here)", o.packed, db->h.ref_ambiguity);
+    if (o.exclude_self) biomcmc_error ("-x is not available with --packed in this version: the name filter changes which references share a batch");
+    if (db->h.side_row_ints != (uint32_t) uvaia_gpu_db_side_row_ints () || db->h.tile_bytes != uvaia_gpu_db_tile_bytes (gpu)) biomcmc_error ("packed database %s does not match this engine's tile layout", o.packed);
+    const uint64_t n = db->h.n_ref, chunk_tiles = 256;
+    if (uvaia_gpu_db_reserve (gpu, (size_t) n)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    for (uint64_t t = 0; t < db->h.n_tiles; t += chunk_tiles) {
+      const uint64_t nt = (db->h.n_tiles - t < chunk_tiles) ? db->h.n_tiles - t : chunk_tiles;
+      const uint64_t first = t * 64, cnt = (first + nt * 64 > n) ? n - first : nt * 64;
+      if (uvaia_gpu_db_append_packed (gpu, uvdb_tile_planes (db, t), db->non_n + first, uvdb_tile_side_rows (db, t), (int) cnt)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    }
+    count = (int) n;
+    fprintf (stderr, "Loaded %d packed sequences from %s in %.3lf secs;\n", count, o.packed, biomcmc_update_elapsed_time (time0));
+    uint8_t *ent = (uint8_t *) biomcmc_malloc ((size_t) (n ? n : 1));
+    if (n && uvaia_gpu_search_resident (gpu, (size_t) o.pool, 0, ent)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    char *text = (char *) biomcmc_malloc ((size_t) query->aln->nchar + 1);
+    for (uint64_t i = 0; i < n; i++) if (ent[i]) {     /* dump every sequence that entered some heap, in stream order */
+      n_output++;
+      uvdb_unpack_reference (db, i, text);
+      write_fasta_record (outstream, uvdb_name (db, i), text);
+      name_table_set (&names, (int64_t) i, uvdb_name (db, i));
+    }
+    free (text); free (ent);
+    fprintf (stderr, "Total of %d sequences searched; %d saved sequences include closest neighbours and intermediate. %.3lf secs elapsed. \n", count, n_output, biomcmc_update_elapsed_time (time1));
+    uvdb_close_reader (db);
+  }
   for (int j = 0; j < o.n_ref; j++) {
     readfasta_t rfas = new_readfasta (o.ref[j]);
     bool end_of_file = false;

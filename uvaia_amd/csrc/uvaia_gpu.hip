@@ -256,6 +256,44 @@ __global__ __launch_bounds__(256) void pack_refs_kernel(const uint8_t *__restric
   if (bad) atomicOr(errflag, 1);
 }
 
+// Packed interchange form -> this context's planes.  The on-disk database (uvaia_amd/csrc/host/uvdb.h) always holds the four
+// IUPAC planes; a default-mode context copies them as they are, an --acgt context re-codes them to (lo, hi, isACGT).  Also
+// writes the per-reference total the two-counter scan subtracts from (valid sites / ACGT sites).  One block per tile.
+template <int P>
+__global__ __launch_bounds__(256) void import_tiles_kernel(const uint4 *src, int W4, uint4 *dst /* P == 4: may be NULL = planes are in place already */, long long tile_base,
+                                                            int *__restrict__ tot_out)
+{
+  __shared__ int partial[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long tile = tile_base + blockIdx.x;
+  const uint4 *t = src + (size_t)blockIdx.x * W4 * 4 * 64 + lane;
+  uint4 *o = dst + (size_t)tile * W4 * P * 64 + lane;
+  int tot = 0;
+  for (int w4 = wv; w4 < W4; w4 += 4) {
+    const uint4 pA = t[(size_t)(w4 * 4 + 0) * 64], pC = t[(size_t)(w4 * 4 + 1) * 64], pG = t[(size_t)(w4 * 4 + 2) * 64], pT = t[(size_t)(w4 * 4 + 3) * 64];
+    if (P == 4) {
+      if (dst) { o[(size_t)(w4 * 4 + 0) * 64] = pA; o[(size_t)(w4 * 4 + 1) * 64] = pC; o[(size_t)(w4 * 4 + 2) * 64] = pG; o[(size_t)(w4 * 4 + 3) * 64] = pT; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) tot += __popc(u4c(pA, j) | u4c(pC, j) | u4c(pG, j) | u4c(pT, j));
+    } else {
+      uint32_t L[4], H[4], I[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t a = u4c(pA, j), cc = u4c(pC, j), g = u4c(pG, j), tt = u4c(pT, j);
+        const uint32_t par = a ^ cc ^ g ^ tt, three = (a & cc & (g | tt)) | (g & tt & (a | cc));
+        I[j] = par & ~three; L[j] = (cc | tt) & I[j]; H[j] = (g | tt) & I[j];
+        tot += __popc(I[j]);
+      }
+      o[(size_t)(w4 * 3 + 0) * 64] = make_uint4(L[0], L[1], L[2], L[3]);
+      o[(size_t)(w4 * 3 + 1) * 64] = make_uint4(H[0], H[1], H[2], H[3]);
+      o[(size_t)(w4 * 3 + 2) * 64] = make_uint4(I[0], I[1], I[2], I[3]);
+    }
+  }
+  partial[wv][lane] = tot;
+  __syncthreads();
+  if (wv == 0) tot_out[tile * 64 + lane] = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // device: the pair scan (dominant kernel)
 // ------------------------------------------------------------------------------------------------------------
@@ -1718,6 +1756,27 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   return 0;
 }
 
+// planes derived for the open query set (column-compressed scan) for the whole tiles that hold slots slot0 .. slot0 + n_ref - 1
+int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref)
+{
+  if (c->fullscan || n_ref <= 0) return 0;
+  const bool is_db = (tiles == c->d_db);
+  uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
+  int *tote = is_db ? c->d_db_tote : c->d_batch_tote;
+  uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
+  const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
+  const int nblk = (int)(t1 - t0 + 1);
+  if (c->acgt) {
+    hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
+    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
+  } else {
+    hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
+    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // stage + pack n_ref rows (either scattered pointers or one pitched block) into `tiles` starting at slot0
 int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t rows_pitch, const int *non_n, int n_ref,
               uint4 *tiles, int *nonn_dev, int *amb_dev, int *tot_dev, long long slot0)
@@ -1739,22 +1798,7 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
     if (non_n) HIPCHK(c, hipMemcpyAsync(nonn_dev + s0, non_n + done, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // h_stage is reused by the next round
   }
-  if (!c->fullscan && n_ref > 0) {   // planes derived for this query set (column-compressed scan): whole tiles touched by the append
-    const bool is_db = (tiles == c->d_db);
-    uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
-    int *tote = is_db ? c->d_db_tote : c->d_batch_tote;
-    uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
-    const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
-    const int nblk = (int)(t1 - t0 + 1);
-    if (c->acgt) {
-      hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-      if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
-    } else {
-      hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-      if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
-    }
-    HIPCHK(c, hipGetLastError());
-  }
+  { int rc = derive_rows(c, tiles, slot0, n_ref); if (rc) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));     // scans may start on another stream: the packed and derived planes must be complete
   int bad = 0;
   HIPCHK(c, hipMemcpy(&bad, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -2144,6 +2188,77 @@ int uvaia_gpu_db_append_block(uvaia_gpu_ctx *c, const char *rows, size_t pitch, 
 }
 
 size_t uvaia_gpu_db_size(const uvaia_gpu_ctx *c) { return c ? c->db_n : 0; }
+
+int uvaia_gpu_db_clear(uvaia_gpu_ctx *c)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (!c->d_db || !c->db_n) { c->db_n = 0; return 0; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
+  const size_t tiles = (c->db_n + 63) / 64;       // lanes past the last reference of a tile must read as zero planes
+  HIPCHK(c, hipMemsetAsync(c->d_db, 0, tiles * (size_t)c->W4 * c->P * 64 * sizeof(uint4), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_db_nonn, 0, tiles * 64 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_db_tot, 0, tiles * 64 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_db_amb, 0, tiles * 64 * AMB_ROW * sizeof(int), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->db_n = 0;
+  return 0;
+}
+
+size_t uvaia_gpu_db_tile_bytes(const uvaia_gpu_ctx *c) { return c ? (size_t)c->W4 * 4 * 64 * sizeof(uint4) : 0; }
+int uvaia_gpu_db_side_row_ints(void) { return AMB_ROW; }
+
+int uvaia_gpu_db_export(uvaia_gpu_ctx *c, size_t first_tile, size_t n_tiles, void *planes, int *non_n, int *side_rows)
+{
+  if (!c || !planes || !non_n || !side_rows) return UVAIA_GPU_EINVAL;
+  if (c->acgt) return fail(c, UVAIA_GPU_ESTATE, "the interchange form is the four IUPAC planes: export from a default-mode context");
+  if ((first_tile + n_tiles) * 64 > ((c->db_n + 63) / 64) * 64) return fail(c, UVAIA_GPU_EINVAL, "tiles %zu..%zu lie outside the database", first_tile, first_tile + n_tiles);
+  if (!n_tiles) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t tb = uvaia_gpu_db_tile_bytes(c);
+  HIPCHK(c, hipMemcpy(planes, reinterpret_cast<const char *>(c->d_db) + first_tile * tb, n_tiles * tb, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(non_n, c->d_db_nonn + first_tile * 64, n_tiles * 64 * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(side_rows, c->d_db_amb + first_tile * 64 * AMB_ROW, n_tiles * 64 * AMB_ROW * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int uvaia_gpu_db_append_packed(uvaia_gpu_ctx *c, const void *planes, const int *non_n, const int *side_rows, int n_ref)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (n_ref < 0) return fail(c, UVAIA_GPU_EINVAL, "negative count");
+  if (n_ref == 0) return 0;
+  if (!planes || !non_n || (!c->acgt && !side_rows)) return fail(c, UVAIA_GPU_EINVAL, "NULL packed arrays");
+  if (c->db_n % 64) return fail(c, UVAIA_GPU_ESTATE, "packed tiles can only follow a whole number of tiles (database holds %zu references)", c->db_n);
+  if (c->db_n + (size_t)n_ref > c->db_cap) {
+    if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "database capacity %zu exceeded: call uvaia_gpu_db_reserve first", c->db_cap);
+    int rc = uvaia_gpu_db_reserve(c, (size_t)n_ref); if (rc) return rc;
+  }
+  const size_t tb = uvaia_gpu_db_tile_bytes(c), n_tiles = ((size_t)n_ref + 63) / 64;
+  const long long t0 = (long long)(c->db_n / 64);
+  if (!c->acgt) {     // same form as the resident planes: straight into place, then the totals
+    HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->d_db) + (size_t)t0 * tb, planes, n_tiles * tb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((import_tiles_kernel<4>), dim3((unsigned)n_tiles), dim3(256), 0, c->stream, c->d_db + (size_t)t0 * c->W4 * 4 * 64, c->W4, (uint4 *)nullptr, t0, c->d_db_tot);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->d_db_amb + (size_t)t0 * 64 * AMB_ROW, side_rows, n_tiles * 64 * AMB_ROW * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  } else {            // re-code through a staging buffer, a few tiles at a time
+    const size_t chunk = 64;
+    uint4 *d_tmp = nullptr;
+    HIPCHK(c, hipMalloc(&d_tmp, chunk * tb));
+    for (size_t a = 0; a < n_tiles; a += chunk) {
+      const size_t m = std::min(chunk, n_tiles - a);
+      hipError_t e = hipMemcpyAsync(d_tmp, reinterpret_cast<const char *>(planes) + a * tb, m * tb, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) { hipLaunchKernelGGL((import_tiles_kernel<3>), dim3((unsigned)m), dim3(256), 0, c->stream, d_tmp, c->W4, c->d_db, t0 + (long long)a, c->d_db_tot); e = hipGetLastError(); }
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) { hipFree(d_tmp); return fail(c, UVAIA_GPU_EHIP, "import of packed tiles: %s", hipGetErrorString(e)); }
+    }
+    hipFree(d_tmp);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_db_nonn + (size_t)t0 * 64, non_n, n_tiles * 64 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  int rc = derive_rows(c, c->d_db, (long long)c->db_n, n_ref); if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->db_n += (size_t)n_ref;
+  return 0;
+}
 
 int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, uint8_t *entered)
 {

@@ -81,9 +81,12 @@ def main():
     gen = hostlib.Synth(args.nchar, seed=args.seed, preset=args.preset)
     qseqs, _ = gen.generate_bytes(QUERY_INDEX0, args.queries)
     qnames = ["query_%d" % i for i in range(args.queries)]
+    t_q0 = time.time()
     pq = hostlib.PreparedQuery(qseqs, qnames, acgt=(args.mode == "acgt"))
+    t_q1 = time.time()
     pool = min(args.pool, args.refs)
     eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank)
+    t_q2 = time.time()
     if args.qt:
         eng.set_query_tile(args.qt)
     eng.db_reserve(args.refs)
@@ -245,7 +248,8 @@ def main():
                                     + "%d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d")
                                    % (pq.ntax, args.refs, args.nchar, "4-bit IUPAC planes" if args.mode == "iupac" else "2-bit + validity planes (--acgt)", args.nbest, pool),
                        "queries": pq.ntax, "refs_per_gpu": args.refs, "nchar": args.nchar, "nbest": args.nbest, "pool": pool,
-                       "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2)},
+                       "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2),
+                       "query_prepare_s": round(t_q1 - t_q0, 2), "engine_open_s": round(t_q2 - t_q1, 2)},
             "roofline": roofline,
             "replay": {"admissions_per_step": admitted // max(1, args.steps + args.warmup), "on_demand_per_step": demanded // max(1, args.steps + args.warmup),
                        "dense_rescans_per_step": dense_rescans // max(1, args.steps + args.warmup)},

@@ -91,6 +91,7 @@ struct uvaia_gpu_ctx {
   uint2 *d_sdir = nullptr;       // [nq_pad/16] {first dword of the tile's stream, number of group records}
   int NP = 0, NP4 = 0;
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
+  int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
   int scan_parts = 3;            // timing experiments only (UVAIA_GPU_SCAN_PARTS): bit 0 = polymorphic loop, bit 1 = constant/validity loop
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
@@ -1325,10 +1326,10 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
                                                       const uint4 *__restrict__ db, long long tile_first, int W4,
                                                       const uint32_t *__restrict__ qfull, const int *__restrict__ amb_q,
                                                       unsigned long long *__restrict__ stats, int q_first, const int *__restrict__ tmin,
-                                                      const int *__restrict__ mpbuf, int lq_words)
+                                                      const int *__restrict__ mpbuf, int lq_words, int prio_)
 {
   extern __shared__ int h[];
-  __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
+  if (prio_) __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
   const int q = blockIdx.x + q_first, lane = threadIdx.x;
   int *hg = heap_g + (size_t)q * (k + 1) * HEAP_ENTRY;
   int n = min(max(n_g[q], 0), k), T = T_g[q];       // clamp: an imported state blob is external input
@@ -1745,7 +1746,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
                                     c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int *)nullptr, \
-                                    c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words)
+                                    c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1977,6 +1978,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         c->need_e_groups += (u & 0xFFFFu) != 0; c->need_v_groups += (u >> 16) != 0; c->need_g_groups += uy != 0;
       }
       { const char *ep = getenv("UVAIA_GPU_SCAN_PARTS"); if (ep) c->scan_parts = atoi(ep); }
+      { const char *ep = getenv("UVAIA_GPU_REPLAY_PRIO"); if (ep) c->replay_prio = atoi(ep); }
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
@@ -2458,7 +2460,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int *)nullptr, \
-                                  c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words)
+                                  c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--qt", type=int, default=0, help="query tile of the scan kernel (8/16/32, 0 = default)")
     ap.add_argument("--cpu-refs", type=int, default=1536, help="references in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-refs-1thread", type=int, default=48, help="sample of the single-thread CPU baseline")
+    ap.add_argument("--multi", choices=["shards", "ring"], default="shards",
+                    help="N > 1: 'shards' = every GPU holds the whole database and a range of the queries (no data-path exchange); "
+                         "'ring' = every GPU holds 1/N of the database, heap state handed rank to rank (uvaia_amd/ring.py)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
     return ap.parse_args()
 
@@ -84,16 +87,19 @@ def main():
     t_q0 = time.time()
     pq = hostlib.PreparedQuery(qseqs, qnames, acgt=(args.mode == "acgt"))
     t_q1 = time.time()
-    pool = min(args.pool, args.refs)
+    shard_mode = world > 1 and args.multi == "shards"
+    local_refs = world * args.refs if shard_mode else args.refs      # query shards: every rank holds (and scans) the whole stream
+    pool = min(args.pool, local_refs)
     eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank)
     t_q2 = time.time()
     if args.qt:
         eng.set_query_tile(args.qt)
-    eng.db_reserve(args.refs)
+    eng.db_reserve(local_refs)
     t0 = time.time()
-    from uvaia_amd import ring
-    # block-cyclic shard: stripe s (= one pool of world*pool references of the stream) = slice s of rank 0, 1, ...
-    slices = ring.block_cyclic_layout(args.refs, pool, rank, world)
+    from uvaia_amd import ring, shards
+    # ring: block-cyclic shard, stripe s (= one pool of world*pool references of the stream) = slice s of rank 0, 1, ...
+    # shards: the whole stream on every rank
+    slices = [ring.Slice(0, local_refs, 0)] if shard_mode else ring.block_cyclic_layout(args.refs, pool, rank, world)
     first = slices[0].ordinal0
     chunk = 8192
     for sl in slices:
@@ -104,15 +110,19 @@ def main():
     load_s = time.time() - t0
     bytes_per_ref = eng.packed_bytes_per_ref()
     on_gpu = backend == "nccl"
-    comm = ring.TorchRingComm(dist, rank, world, cuda=on_gpu) if dist is not None else None
+    comm = ring.TorchRingComm(dist, rank, world, cuda=on_gpu) if (dist is not None and not shard_mode) else None
     nbytes = eng.state_bytes()
     cons = len(pq.idx_c) > 0
+    q0, q1 = shards.query_shard(pq.ntax, rank, world) if shard_mode else (0, pq.ntax)
+    allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons) else None
 
     # ---- timed region
     def step():
         eng.reset()
         if world == 1:
             eng.search_resident(pool, ordinal0=0, want_entered=False)
+        elif shard_mode:   # no data-path exchange (one all-reduced int per pool if the query set has complete constant columns)
+            shards.run_query_shard(eng, q0, q1, local_refs, pool, cons, allmax)
         else:   # scans run concurrently on all ranks; the heap state visits the ranks in stream order, pipelined by query group
             ring.run_ring_grouped(eng, comm, rank, world, slices, pq.ntax, cons,
                                   lambda nb: ring.TorchStateBuffer(nb, "cuda" if on_gpu else "cpu"))
@@ -142,7 +152,7 @@ def main():
     W = (args.nchar + 31) // 32
     fullscan = os.environ.get("UVAIA_GPU_FULLSCAN", "0") not in ("", "0")
     ops_per_pair_word = (15 if args.mode == "iupac" else 8) if fullscan else 6
-    valu_ops = float(args.refs) * pq.ntax * W * ops_per_pair_word * args.steps       # lane-ops in the timed region
+    valu_ops = float(local_refs) * (q1 - q0) * W * ops_per_pair_word * args.steps    # lane-ops in the timed region (this rank)
     valu_rate = valu_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     # The column-compressed scan does not read the 4-bit records themselves but planes derived from them for this query set
     # (E and V planes + the gathered polymorphic columns): fewer bytes per reference than the packed record.
@@ -154,7 +164,7 @@ def main():
     # 2 bits + validity plane), each reference byte once per launch.  The bytes THIS kernel has to read (derived planes, only the
     # word groups some query tile needs) are fewer; the rate on those is given next to it and is the one PMC FETCH_SIZE verifies.
     survey_bytes_per_ref = (args.nchar * 4 + 7) // 8 if args.mode == "iupac" else (args.nchar * 2 + 7) // 8 + (args.nchar + 7) // 8
-    refs_per_launch = float(args.refs) * args.steps / launches
+    refs_per_launch = float(local_refs) * args.steps / launches
     achieved = refs_per_launch * survey_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     on_kernel_bytes = refs_per_launch * kernel_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {
@@ -183,7 +193,7 @@ def main():
                 # instruction issue: wave-instructions per (16 queries x 64 references) wave from the committed SQ passes, times the
                 # waves of the timed region, over the measured scan time; peak = tools/issue_rate.hip (VALU + SALU mixed, whole chip)
                 per_wave = pm["wave_instructions_all_dispatches"] / pm["instruction_mix_all_dispatches"]["SQ_WAVES"]
-                waves = ((pq.ntax + 15) // 16) * ((args.refs + 63) // 64) * args.steps
+                waves = ((q1 - q0 + 15) // 16) * ((local_refs + 63) // 64) * args.steps
                 rate = per_wave * waves / (scan_ms * 1e-3) / 1e9
                 roofline["issue"] = {"wave_instructions_per_wave": round(per_wave), "achieved": round(rate, 1), "peak": 1037.0, "unit": "G wave-instr/s",
                                      "frac": round(rate / 1037.0, 3), "source": "profiles/r01_pmc_traffic.json, profiles/r01_issue_rate_microbench.txt"}
@@ -241,7 +251,10 @@ def main():
             "metric": "ref-seqs scored/sec", "value": round(value, 2), "unit": "ref-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "multi_gpu": None if world == 1 else "block-cyclic slices of %d refs, concurrent scans, heap state (%d B in %d per-query-group blobs) pipelined rank to rank (RCCL isend/irecv), exact" % (pool, nbytes, world),
+            "multi_gpu": None if world == 1 else
+            ("query shards: every GPU holds all %d references and the heaps of %d of the %d queries (column classes from the whole set); no data-path exchange%s; exact"
+             % (local_refs, q1 - q0, pq.ntax, ", one all-reduced int per pool" if cons else "")) if shard_mode else
+            "block-cyclic slices of %d refs, concurrent scans, heap state (%d B in %d per-query-group blobs) pipelined rank to rank (RCCL isend/irecv), exact" % (pool, nbytes, world),
             "dtype": "u32 bit-planes / int32 counts", "data": "synthetic (seed %d, preset %d)" % (args.seed, args.preset),
             "config": {"workload": (("BASELINE config[1]: " if (pq.ntax, args.refs, args.nchar, args.nbest) == (1000, 100000, 29903, 100) else
                                      "BASELINE config[2]: " if (pq.ntax, args.refs, args.nchar, args.nbest, args.mode) == (10000, 1000000, 29903, 100, "acgt") else "")

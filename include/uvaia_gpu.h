@@ -147,6 +147,19 @@ int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, d
 int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int reset);
 /* tuning knob: queries held per pass of the scan kernel (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
+/* ---- query shards: several GPUs, each holding the whole database and the heaps of a contiguous range of the queries.  The
+ * per-query machines of src/nearest.c:435-510 are independent given the column classes of the WHOLE query set (which the context
+ * was opened with), so a rank scans and replays only its range; no data-path exchange.  The one coupling between queries is the
+ * batch snapshot cq->max_incompatible = max over ALL heaps (src/nearest.c:290-291), which matters only when the query set has
+ * constant-and-complete columns (n_idx_c > 0): then the driver runs pool by pool, all-reduces (max) uvaia_gpu_max_tolerance()
+ * over the ranks and passes the result as `snapshot`.
+ *   set_active_queries: resident and slice calls act on queries [q0, q1) only (q0 a multiple of 16); push/ball need the full range
+ *   search_resident_pool: one batch [first, first+n) of the resident database, n <= max_pool; snapshot < 0 = take it from this
+ *                         context's active queries */
+int uvaia_gpu_set_active_queries (uvaia_gpu_ctx *ctx, int q0, int q1);
+int uvaia_gpu_max_tolerance (uvaia_gpu_ctx *ctx, int *out);
+int uvaia_gpu_search_resident_pool (uvaia_gpu_ctx *ctx, size_t first, size_t n, int64_t ordinal0, int snapshot);
+
 /* ---- packed interchange form (packed on-disk database).  Replaces, for a database that was packed once,
  * the serial text path of the reference (readfasta_next src/fastaseq.c:422-474 + the slot filling of src/nearest.c:251-286 +
  * quick_count_sequence_non_N src/fastaseq.c:642-648): tiles of 64 references, each uvaia_gpu_db_tile_bytes() long, laid out

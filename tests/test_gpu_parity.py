@@ -162,6 +162,59 @@ def test_packed_interchange_form_round_trip(synth):
             eng.db_export()
 
 
+@pytest.mark.parametrize("acgt,gappy", [(False, False), (True, False), (False, True)])
+def test_query_shards_equal_one_context(synth, acgt, gappy):
+    """Query shards (uvaia_amd/shards.py): contexts opened with the WHOLE query set, each active on a range of it and holding the
+    whole database, give the heaps of one context over all queries -- with the snapshot exchanged pool by pool when the query set
+    has constant-and-complete columns.  Three shards on one GPU, driven in lockstep."""
+    from uvaia_amd import shards
+    refs, qs = synth
+    qs = list(qs)
+    if gappy:
+        qs = [bytearray(s) for s in qs]
+        for i, s in enumerate(qs[:10]):
+            a = i * len(s) // 10
+            s[a:a + len(s) // 10 + 1] = b"N" * len(s[a:a + len(s) // 10 + 1])
+        qs = [bytes(s) for s in qs]
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt, ambig_q=1.0)
+    cons = len(q.idx_c) > 0
+    assert cons == (not gappy)
+    pool, nbest, world = 100, 7, 3
+    rows_1, T_1, ent_1 = _gpu_search(q, refs, pool, nbest)
+    engines = [capi.Engine.from_query(q, nbest=nbest, max_pool=512) for _ in range(world)]
+    try:
+        cuts = [shards.query_shard(q.ntax, r, world) for r in range(world)]
+        assert cuts == [(0, 16), (16, 32), (32, 40)]
+        for e in engines:
+            e.db_append(refs)
+        if not cons:
+            for e, (q0, q1) in zip(engines, cuts):
+                shards.run_query_shard(e, q0, q1, len(refs), pool, cons)
+        else:       # lockstep emulation of the all-reduce: what every rank would receive is the maximum over the ranks
+            for e, (q0, q1) in zip(engines, cuts):
+                e.set_active_queries(q0, q1)
+                e.entered_flags(clear=True)
+            for a in range(0, len(refs), pool):
+                snap = max(e.max_tolerance() for e in engines)
+                for e in engines:
+                    e.search_resident_pool(a, min(pool, len(refs) - a), a, snap)
+        ent = np.zeros(len(refs), dtype=np.uint8)
+        for e, (q0, q1) in zip(engines, cuts):
+            n, T, sc, od = e.drain()
+            rows = capi.finalise_heaps(n, sc, od)
+            assert rows[q0:q1] == rows_1[q0:q1]
+            assert list(T)[q0:q1] == T_1[q0:q1]
+            ent |= e.entered_flags()
+            with pytest.raises(capi.GpuError):          # streamed batches act on the whole query set
+                e.push(refs[:10])
+        assert np.array_equal(ent, ent_1)               # a reference is dumped if it entered a heap on any rank
+        with pytest.raises(capi.GpuError):
+            engines[0].set_active_queries(8, 24)        # ranges start on a query tile
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_query_tile_sizes_agree(synth):
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"))

@@ -20,6 +20,7 @@ SYMBOLS = [
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
     "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
     "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear",
+    "uvaia_gpu_set_active_queries", "uvaia_gpu_max_tolerance", "uvaia_gpu_search_resident_pool",
 ]
 
 
@@ -100,6 +101,9 @@ def load_library():
         "uvaia_gpu_scan_bytes_per_ref": (C.c_size_t, [vp]),
         "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
+        "uvaia_gpu_set_active_queries": (C.c_int, [vp, C.c_int, C.c_int]),
+        "uvaia_gpu_max_tolerance": (C.c_int, [vp, pi]),
+        "uvaia_gpu_search_resident_pool": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int64, C.c_int]),
         "uvaia_gpu_db_tile_bytes": (C.c_size_t, [vp]),
         "uvaia_gpu_db_clear": (C.c_int, [vp]),
         "uvaia_gpu_db_side_row_ints": (C.c_int, []),
@@ -223,6 +227,17 @@ class Engine:
 
     def db_size(self):
         return self.L.uvaia_gpu_db_size(self.ctx)
+
+    def set_active_queries(self, q0, q1):
+        self._chk(self.L.uvaia_gpu_set_active_queries(self.ctx, int(q0), int(q1)))
+
+    def max_tolerance(self):
+        v = C.c_int(0)
+        self._chk(self.L.uvaia_gpu_max_tolerance(self.ctx, C.byref(v)))
+        return v.value
+
+    def search_resident_pool(self, first, n, ordinal0, snapshot=-1):
+        self._chk(self.L.uvaia_gpu_search_resident_pool(self.ctx, int(first), int(n), int(ordinal0), int(snapshot)))
 
     def db_clear(self):
         self._chk(self.L.uvaia_gpu_db_clear(self.ctx))

@@ -91,6 +91,7 @@ struct uvaia_gpu_ctx {
   uint2 *d_sdir = nullptr;       // [nq_pad/16] {first dword of the tile's stream, number of group records}
   int NP = 0, NP4 = 0;
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
+  int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
   int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
   int scan_parts = 3;            // timing experiments only (UVAIA_GPU_SCAN_PARTS): bit 0 = polymorphic loop, bit 1 = constant/validity loop
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
@@ -667,13 +668,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                      const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
                                                      const int *__restrict__ tot_e, const int *__restrict__ tot_v,
                                                      int2 *__restrict__ out, int ppad, int n_qtiles, int *__restrict__ tmin, int r_lo, int r_hi,
-                                                     int *__restrict__ mp_out, int parts)
+                                                     int *__restrict__ mp_out, int parts, int qtile_first)
 {
   static_assert(QT == 16, "stream offsets are laid out for tiles of 16 queries");
   __shared__ uint32_t lacc[4][QT + 1][64];                     // per wave: one packed counter per (query, lane) + a scratch row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int qtile, group;
   if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
+  qtile += qtile_first;                                        // only the active query tiles are scanned (query shards)
   const int trel = group * 4 + wave;
   if (trel >= n_tiles) return;
   const int q0 = qtile * QT;
@@ -1372,7 +1374,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   const bool use_tmin = !CONS && tmin != nullptr;
   const int *tmrow = use_tmin ? tmin + (size_t)q * (ppad >> 6) : nullptr;
   const int n_slice_tiles = (r_end + 63) >> 6;
-  constexpr int D = 4;
+  constexpr int D = 8;
   for (int tb = 0; tb < n_slice_tiles; tb += 64) {
     int tm = 0x7fffffff;
     if (tb + lane < n_slice_tiles) tm = use_tmin ? tmrow[tb + lane] : -1;
@@ -1669,10 +1671,10 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
-    const int nqt3 = (c->nq + 15) / 16;
+    const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts);
+    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1852,7 +1854,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
 
   uvaia_gpu_ctx *c = new uvaia_gpu_ctx();
   c->device = device;
-  c->nq = q->n_query; c->nchar = q->nchar; c->acgt = q->acgt ? 1 : 0; c->trim = q->trim; c->n_idx_c = q->n_idx_c;
+  c->nq = q->n_query; c->act_q0 = 0; c->act_q1 = q->n_query; c->nchar = q->nchar; c->acgt = q->acgt ? 1 : 0; c->trim = q->trim; c->n_idx_c = q->n_idx_c;
   c->P = c->acgt ? 3 : 4; c->NQ = c->acgt ? 4 : 6;
   c->W = (c->nchar + 31) / 32; c->W4 = (c->W + 3) / 4;
   c->k = heap_size < 2 ? 2 : heap_size;                      // src/min_heap.c:58
@@ -2107,6 +2109,7 @@ int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, i
   if (!c) return UVAIA_GPU_EINVAL;
   if (n_ref < 0 || (n_ref > 0 && !seq)) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
+  if (c->act_q0 != 0 || c->act_q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "streamed batches act on the whole query set: query shards use the resident calls");
   if (n_ref == 0) return 0;
   int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
@@ -2262,6 +2265,50 @@ int uvaia_gpu_db_append_packed(uvaia_gpu_ctx *c, const void *planes, const int *
   return 0;
 }
 
+// Sub-slices of the pools that tile [first, first + n): {first reference, length, opens a pool}.  A pool boundary only retakes
+// the snapshot of the tolerances (src/nearest.c:290-291), which happens at a pool's first sub-slice, so cutting pools is exact.
+struct SubSlice { size_t first, n; bool pool_start; };
+static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first, size_t n, size_t pool)
+{
+  std::vector<SubSlice> subs;
+  // with few queries the replay is negligible and small launches only cost: one slice per pool then.  The sub-slice length is
+  // tuned for 63 query tiles (1 000 queries); with fewer active tiles (query shards) it grows so that a launch still fills the chip
+  const char *env_minq = getenv("UVAIA_GPU_SUBSLICE_MINQ");
+  const int nq_act = c->act_q1 - c->act_q0, nqt = (c->act_q1 + 15) / 16 - c->act_q0 / 16;
+  size_t sub = c->subslice;
+  if (nqt < 63) sub = std::min(pool, (sub * 63 / (size_t)std::max(nqt, 1) + 63) / 64 * 64);
+  if (nq_act < (env_minq ? atoi(env_minq) : 256)) sub = pool;
+  for (size_t a = first; a < first + n; a += pool) {
+    const size_t pe = std::min(first + n, a + pool);
+    // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
+    // one launch, not a full one plus a sliver whose launch latency and replay would sit on the critical path
+    const size_t len = pe - a, ns = std::max<size_t>(1, (len + sub / 2) / sub);
+    const size_t each = ((len + ns - 1) / ns + 63) / 64 * 64;
+    for (size_t x = a; x < pe; x += each) subs.push_back({x, std::min(each, pe - x), x == a});
+  }
+  return subs;
+}
+
+// Two streams and a ring of NBUF counter buffers: the scan needs no state, so it runs up to NBUF-1 slices ahead of the replay.
+// snapshot >= 0: the first pool's snapshot is given (query shards: the maximum over all ranks); only valid for a single pool.
+static int run_subslices(uvaia_gpu_ctx *c, const std::vector<SubSlice> &subs, int64_t ordinal_of_db0, int snapshot)
+{
+  const size_t ns = subs.size();
+  size_t issued = 0;
+  for (size_t i = 0; i < ns; i++) {
+    while (issued < ns && issued < i + NBUF) {          // keep the scan stream fed
+      int rc = uvaia_gpu_slice_scan(c, subs[issued].first, subs[issued].n, (int)(issued % NBUF));
+      if (rc) return rc;
+      issued++;
+    }
+    int take = subs[i].pool_start ? 1 : 0;
+    if (take && snapshot >= 0) { HIPCHK(c, hipMemcpyAsync(c->d_snap, &snapshot, sizeof(int), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); take = 0; }
+    int rc = uvaia_gpu_slice_replay(c, (int)(i % NBUF), ordinal_of_db0 + (long long)subs[i].first, take);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, uint8_t *entered)
 {
   if (!c) return UVAIA_GPU_EINVAL;
@@ -2269,33 +2316,8 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
   if (!c->db_n) return 0;
   HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
   if (!c->fullscan) {
-    // Two streams and a ring of NBUF counter buffers: the scan needs no state, so it runs up to NBUF-1 slices ahead of the
-    // gate/replay.  Each pool is cut into sub-slices; that is exact because the only thing a pool boundary does is retake the
-    // snapshot of the tolerances (src/nearest.c:290-291), which happens at the first sub-slice of a pool only.
-    struct Sub { size_t first, n; bool pool_start; };
-    std::vector<Sub> subs;
-    // with few queries the replay is negligible and small launches only cost: one slice per pool then
-    const char *env_minq = getenv("UVAIA_GPU_SUBSLICE_MINQ");
-    const size_t sub = (c->nq >= (env_minq ? atoi(env_minq) : 256)) ? c->subslice : pool;
-    for (size_t a = 0; a < c->db_n; a += pool) {
-      const size_t pe = std::min(c->db_n, a + pool);
-      // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
-      // one launch, not a full one plus a sliver whose launch latency and replay would sit on the critical path
-      const size_t len = pe - a, ns = std::max<size_t>(1, (len + sub / 2) / sub);
-      const size_t each = ((len + ns - 1) / ns + 63) / 64 * 64;
-      for (size_t x = a; x < pe; x += each) subs.push_back({x, std::min(each, pe - x), x == a});
-    }
-    const size_t ns = subs.size();
-    size_t issued = 0;
-    for (size_t i = 0; i < ns; i++) {
-      while (issued < ns && issued < i + NBUF) {          // keep the scan stream fed
-        int rc = uvaia_gpu_slice_scan(c, subs[issued].first, subs[issued].n, (int)(issued % NBUF));
-        if (rc) return rc;
-        issued++;
-      }
-      int rc = uvaia_gpu_slice_replay(c, (int)(i % NBUF), ordinal0 + (long long)subs[i].first, subs[i].pool_start ? 1 : 0);
-      if (rc) return rc;
-    }
+    int rc = run_subslices(c, plan_subslices(c, 0, c->db_n, pool), ordinal0, -1);
+    if (rc) return rc;
   } else
   for (size_t a = 0; a < c->db_n; a += pool) {
     const size_t b = std::min(c->db_n, a + pool);
@@ -2311,6 +2333,14 @@ int uvaia_gpu_search_resident(uvaia_gpu_ctx *c, size_t pool, int64_t ordinal0, u
     return collect_events(c);
   }
   return 0;
+}
+
+int uvaia_gpu_search_resident_pool(uvaia_gpu_ctx *c, size_t first, size_t n, int64_t ordinal0, int snapshot)
+{ // one batch ("pool") [first, first + n) of the resident database; entered flags accumulate (uvaia_gpu_entered_flags)
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "per-pool search needs the default scan");
+  if (n < 1 || n > c->max_pool || first + n > c->db_n) return fail(c, UVAIA_GPU_EINVAL, "pool [%zu,+%zu) outside the database or above max_pool=%zu", first, n, c->max_pool);
+  return run_subslices(c, plan_subslices(c, first, n, n), ordinal0 - (int64_t)first, snapshot);
 }
 
 int uvaia_gpu_sync(uvaia_gpu_ctx *c)
@@ -2444,7 +2474,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   if (q0 < 0 || q1 > c->nq || q1 < q0) return fail(c, UVAIA_GPU_EINVAL, "bad query range [%d,%d)", q0, q1);
   const int n_tiles = c->slice_tiles[buf], rb = c->slice_rb[buf], re = c->slice_re[buf];
   const long long tf = c->slice_tf[buf];
-  if (take_snapshot) { hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap); c->slice_cons_done[buf] = false; }
+  if (take_snapshot) { hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T + c->act_q0, c->act_q1 - c->act_q0, c->d_snap); c->slice_cons_done[buf] = false; }
   if (re <= rb || q1 == q0) return 0;
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->scan_done[buf], 0));
   const int ppad = n_tiles * 64;
@@ -2474,7 +2504,30 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
 int uvaia_gpu_slice_buffers(void) { return NBUF; }
 
 int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stripe_start)
-{ return c ? uvaia_gpu_slice_replay_range(c, buf, ordinal0, 0, c->nq, stripe_start) : UVAIA_GPU_EINVAL; }
+{ return c ? uvaia_gpu_slice_replay_range(c, buf, ordinal0, c->act_q0, c->act_q1, stripe_start) : UVAIA_GPU_EINVAL; }
+
+int uvaia_gpu_set_active_queries(uvaia_gpu_ctx *c, int q0, int q1)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (q0 < 0 || q1 > c->nq || q1 <= q0 || (q0 % 16)) return fail(c, UVAIA_GPU_EINVAL, "active queries [%d,%d): need 0 <= q0 < q1 <= %d and q0 a multiple of 16", q0, q1, c->nq);
+  if (c->fullscan || c->scan_variant != 2) { if (q0 != 0 || q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "query shards need the default scan"); }
+  c->act_q0 = q0; c->act_q1 = q1;
+  return 0;
+}
+
+int uvaia_gpu_max_tolerance(uvaia_gpu_ctx *c, int *out)
+{ // max over the active queries of max_incompatible: a rank's contribution to the batch snapshot (src/nearest.c:290-291)
+  if (!c || !out) return UVAIA_GPU_EINVAL;
+  int *d_tmp = nullptr;
+  HIPCHK(c, hipMalloc(&d_tmp, sizeof(int)));
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T + c->act_q0, c->act_q1 - c->act_q0, d_tmp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_tmp);
+  if (e != hipSuccess) return fail(c, UVAIA_GPU_EHIP, "max_tolerance: %s", hipGetErrorString(e));
+  return 0;
+}
 
 int uvaia_gpu_entered_flags(uvaia_gpu_ctx *c, uint8_t *out, int clear)
 { // "entered any heap" flags of the resident database accumulated by slice replays (and by search_resident)
@@ -2490,6 +2543,7 @@ int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radi
   if (!c) return UVAIA_GPU_EINVAL;
   if (n_ref < 0 || (n_ref > 0 && (!seq || !mindist))) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
+  if (c->act_q0 != 0 || c->act_q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "the radius search acts on the whole query set");
   if (n_ref == 0) return 0;
   int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;

@@ -69,7 +69,7 @@ struct uvaia_gpu_ctx {
   hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
   int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
-  int *d_tmin[NBUF] = {};                 // per (query, tile of 64 references): smallest mismatch count, one per counter buffer
+  int2 *d_tmin[NBUF] = {};                // per (query, tile of 64 references): {smallest mismatch count, largest ACGT-match count}, one per counter buffer
   int *d_mp[NBUF] = {};                   // --acgt: mismatches on the polymorphic columns per pair (dist_unique), one per counter buffer
   int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
   long long slice_tf[NBUF] = {};
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                      int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ stream,
                                                      const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
                                                      const int *__restrict__ tot_e, const int *__restrict__ tot_v,
-                                                     int2 *__restrict__ out, int ppad, int n_qtiles, int *__restrict__ tmin, int r_lo, int r_hi,
+                                                     int2 *__restrict__ out, int ppad, int n_qtiles, int2 *__restrict__ tmin, int r_lo, int r_hi,
                                                      int *__restrict__ mp_out, int parts, int qtile_first)
 {
   static_assert(QT == 16, "stream offsets are laid out for tiles of 16 queries");
@@ -794,11 +794,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t pk = my[q * 64];
     const int c0 = (ACGT ? mp_in[(size_t)(q0 + q) * ppad + r] + te : te + NP4 * 128) - (int)(pk & 0xFFFFu), c1 = tv - (int)(pk >> 16);
     out[(size_t)(q0 + q) * ppad + r] = make_int2(c0, c1);
-    // smallest mismatch count of the tile: lets the replay skip tiles that cannot pass the gate (src/nearest.c:488) at all
-    int m = in_batch ? (ACGT ? c0 : c1 - c0) : 0x7fffffff;
+    // Two bounds per tile let the replay skip tiles that cannot admit anything: the smallest mismatch count (the gate of
+    // src/nearest.c:488 needs mismatches < tolerance) and the largest ACGT-match count (a full heap only takes a key that is not
+    // below its worst one, and ACGT matches are the first key: src/min_heap.c:95).  The second is by far the sharper one.
+    const int mm = ACGT ? c0 : c1 - c0, kk = ACGT ? c1 - c0 : c0;
+    int m = in_batch ? mm : 0x7fffffff, k = in_batch ? kk : (int)0x80000000;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-    if (lane == 0) tmin[(size_t)(q0 + q) * (ppad >> 6) + trel] = m;
+    for (int o = 32; o > 0; o >>= 1) { m = min(m, __shfl_xor(m, o)); k = max(k, __shfl_xor(k, o)); }
+    if (lane == 0) tmin[(size_t)(q0 + q) * (ppad >> 6) + trel] = make_int2(m, k);
     __builtin_amdgcn_sched_barrier(0);                                // one query at a time: keeps the epilogue from inflating the register budget
   }
 }
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
                                                       const int *__restrict__ snap_ptr, uint8_t *__restrict__ entered, int k,
                                                       const uint4 *__restrict__ db, long long tile_first, int W4,
                                                       const uint32_t *__restrict__ qfull, const int *__restrict__ amb_q,
-                                                      unsigned long long *__restrict__ stats, int q_first, const int *__restrict__ tmin,
+                                                      unsigned long long *__restrict__ stats, int q_first, const int2 *__restrict__ tmin,
                                                       const int *__restrict__ mpbuf, int lq_words, int prio_)
 {
   extern __shared__ int h[];
@@ -1370,15 +1373,19 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   // admission, and the tolerance only changes through admissions; so the wave walks the tile minima (64 tiles per load) and
   // fetches pair counters only for tiles that can pass the gate now, four tiles in flight.  After an admission that changed
   // the tolerance the set of needed tiles is derived again (a tile skipped earlier may qualify once the tolerance rises).
-  // Exact for any sequence of tolerances.  With consensus counters in play (CONS) every tile is visited.
-  const bool use_tmin = !CONS && tmin != nullptr;
-  const int *tmrow = use_tmin ? tmin + (size_t)q * (ppad >> 6) : nullptr;
+  // Exact for any sequence of tolerances.
+  const bool use_tmin = tmin != nullptr;
+  const int2 *tmrow = use_tmin ? tmin + (size_t)q * (ppad >> 6) : nullptr;
   const int n_slice_tiles = (r_end + 63) >> 6;
   constexpr int D = 8;
   for (int tb = 0; tb < n_slice_tiles; tb += 64) {
-    int tm = 0x7fffffff;
-    if (tb + lane < n_slice_tiles) tm = use_tmin ? tmrow[tb + lane] : -1;
-    unsigned long long P = __ballot(tm < T);
+    int tm = 0x7fffffff, tk = 0x7fffffff;            // tile bounds: smallest mismatch count, largest first key
+    if (tb + lane < n_slice_tiles) { if (use_tmin) { const int2 b_ = tmrow[tb + lane]; tm = b_.x; tk = b_.y; } else tm = -1; }
+    // a tile can admit only if some reference passes the gate and (heap full) some reference's first key reaches the worst kept one
+    // With consensus counters (CONS) a pre-score cut short at the snapshot lowers a pair's mismatch count, but never below the
+    // snapshot, and never raises its first key: the bounds stay valid with "tm < T" widened to "tm < T or snapshot < T".
+    auto needed = [&]() -> unsigned long long { return __ballot((tm < T || (CONS && snap < T)) && (!full || tk >= W[0])); };
+    unsigned long long P = needed();
     while (P) {
       int tsel[D]; int2 c[D]; int4 a[D], rc[D]; int nn[D], m[D], K0[D], K1[D], K2[D], K3[D]; bool valid[D];
       {
@@ -1531,7 +1538,7 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
           // Needed tiles under the new tolerance, after this one.  A lower tolerance only removes tiles: the ones already in
           // flight are processed anyway (their ballots come out empty).  A higher tolerance can add a tile that lies BEFORE
           // the next tile in flight; only then must the group be formed again to keep the stream order.
-          P = __ballot(tm < T) & ~((2ull << tsel[u]) - 1ull);
+          P = needed() & ~((2ull << tsel[u]) - 1ull);
           unsigned long long inflight = 0ull; int last = -1;
 #pragma unroll
           for (int v = 0; v < D; v++) if (v > u && tsel[v] >= 0) { inflight |= (1ull << tsel[v]); last = tsel[v]; }
@@ -1654,7 +1661,7 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
 }
 
 int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream,
-                 int *tmin, int r_lo, int r_hi, int *mp)
+                 int2 *tmin, int r_lo, int r_hi, int *mp)
 {
   if (n_tiles <= 0) return 0;
   if (!stream) stream = c->stream;
@@ -1747,7 +1754,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0]);
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
-                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int *)nullptr, \
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int2 *)nullptr, \
                                     c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
@@ -2041,7 +2048,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_ROW * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_ROW * sizeof(int)));
   if (!c->fullscan) OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
-  OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int)));
+  OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   { const char *env_sub = getenv("UVAIA_GPU_SUBSLICE"); if (env_sub && atol(env_sub) >= 64) c->subslice = (size_t)atol(env_sub); }
   if (c->acgt && !c->fullscan && c->scan_variant == 2) OPENCHK(hipMalloc(&c->d_mp[0], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
@@ -2449,7 +2456,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "ring mode needs the two-counter scan");
   if (first + n > c->db_n || n > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database or above max_pool", first, n);
   if (buf > 0 && !c->d_cntb[buf]) HIPCHK(c, hipMalloc(&c->d_cntb[buf], (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
-  if (!c->d_tmin[buf]) HIPCHK(c, hipMalloc(&c->d_tmin[buf], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int)));
+  if (!c->d_tmin[buf]) HIPCHK(c, hipMalloc(&c->d_tmin[buf], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   if (c->d_mp[0] && !c->d_mp[buf]) HIPCHK(c, hipMalloc(&c->d_mp[buf], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
   const long long tf = (long long)(first / 64);
@@ -2489,7 +2496,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int *)nullptr, \
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int2 *)nullptr, \
                                   c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }

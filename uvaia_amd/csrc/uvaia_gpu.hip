@@ -92,6 +92,8 @@ struct uvaia_gpu_ctx {
   int NP = 0, NP4 = 0;
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
+  int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
+  int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
   int scan_parts = 3;            // timing experiments only (UVAIA_GPU_SCAN_PARTS): bit 0 = polymorphic loop, bit 1 = constant/validity loop
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
@@ -1680,8 +1682,8 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
+    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1743,7 +1745,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   HIPCHK(c, hipGetLastError());
   const double bytes = (double)(r_end - r_begin) * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
   size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
-  const int lq_words = (!c->acgt && !c->fullscan && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;   // query planes cached in LDS
+  const int lq_words = (c->replay_lq && !c->acgt && !c->fullscan && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;   // query planes cached in LDS
   if (c->fullscan) {
     int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
     rc = launch_scan(c, tiles, tile_first, n_tiles, c->d_qp, c->nq, c->d_cnt, ppad, bytes);
@@ -1988,6 +1990,11 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       }
       { const char *ep = getenv("UVAIA_GPU_SCAN_PARTS"); if (ep) c->scan_parts = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_REPLAY_PRIO"); if (ep) c->replay_prio = atoi(ep); }
+      { const char *ep = getenv("UVAIA_GPU_SCAN_LDS_PAD"); if (ep) c->scan_lds_pad = atoi(ep); }
+      { const char *ep = getenv("UVAIA_GPU_REPLAY_LQ"); if (ep) c->replay_lq = atoi(ep); }
+      // Next to a running scan (8 blocks x 16.9 KB of LDS per CU) a replay block with the 22 KB query row fits once per CU, without
+      // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
+      if (c->replay_lq < 0) c->replay_lq = (c->nq < 256) ? 1 : 0;
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
@@ -2303,15 +2310,18 @@ static int run_subslices(uvaia_gpu_ctx *c, const std::vector<SubSlice> &subs, in
   const size_t ns = subs.size();
   size_t issued = 0;
   for (size_t i = 0; i < ns; i++) {
-    while (issued < ns && issued < i + NBUF) {          // keep the scan stream fed
+    const bool serial_ = getenv("UVAIA_GPU_SERIAL") != nullptr;
+    while (issued < ns && issued < i + (serial_ ? 1 : NBUF)) {          // keep the scan stream fed
       int rc = uvaia_gpu_slice_scan(c, subs[issued].first, subs[issued].n, (int)(issued % NBUF));
       if (rc) return rc;
       issued++;
+      if (serial_) hipStreamSynchronize(c->scan_stream);
     }
     int take = subs[i].pool_start ? 1 : 0;
     if (take && snapshot >= 0) { HIPCHK(c, hipMemcpyAsync(c->d_snap, &snapshot, sizeof(int), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); take = 0; }
     int rc = uvaia_gpu_slice_replay(c, (int)(i % NBUF), ordinal_of_db0 + (long long)subs[i].first, take);
     if (rc) return rc;
+    if (serial_) hipStreamSynchronize(c->stream);
   }
   return 0;
 }
@@ -2491,7 +2501,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
     c->slice_cons_done[buf] = true;
   }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
-  const int lq_words = (!c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
+  const int lq_words = (c->replay_lq && !c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
   const int2 *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;

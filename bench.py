@@ -181,6 +181,10 @@ def main():
                  "(VALU popcounts + scalar bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (profiles/r01_sweep_q*.json, DESIGN.md 4.1)") % pq.ntax,
     }
 
+    if achieved > HBM_PEAK_GBS:
+        roofline["frac_note"] = ("the SURVEY figure counts the whole packed record of every reference; with %d queries this kernel reads only the derived "
+                                 "planes of the word groups some query needs (kernel_bytes_per_ref), so the nominal rate exceeds the peak: "
+                                 "frac_on_kernel_bytes is the physical HBM fraction (PMC-verified, profiles/r01_pmc_traffic.json)") % pq.ntax
     # HBM-side traffic of the scan from the committed PMC passes (rocprofv3 cannot run inside this process); only quoted
     # when the run is the configuration those passes measured
     try:

@@ -663,6 +663,8 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 //   record = { w4 * 2048 (byte offset of the group's E plane in the tile) | needE | needV << 1,  n_full4 = ceil(n_full / 4),  n_generic,
 //              w4 * 256 (byte offset of the group's grp[] row) }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
 //            + n_generic x { ~qI & constMask [4],  ~qV (default) / ~qI (--acgt) [4],  LDS offset, 0, 0, 0 }
+//            + word items { ~qI & constMask, ~qV, LDS offset, 0 } of the queries that are dirty in ONE word of the group only, listed word
+//              by word; their four counts sit in bits 4.. of the second header word (5 bits each)
 // qpl[q][p4][L,H,I,-][4]: compressed planes of the polymorphic columns
 template <int QT, bool ACGT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (uint32_t rec = 0; rec < dir.y; rec++) {
       QWords<4> h;
       load_qwords(h, sp);
-      const uint32_t h0 = h.v[0], n_full4 = h.v[1], n_gen = h.v[2];
+      const uint32_t h0 = h.v[0], n_full4 = h.v[1] & 15u, n_words = h.v[1] >> 4, n_gen = h.v[2];
       sp += 4;
       const char *tg = reinterpret_cast<const char *>(t) + (h0 & ~1023u);            // E plane of the group, V plane 1 KiB further
       uint4 pE = make_uint4(0, 0, 0, 0), pV = pE;
@@ -781,6 +783,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             TOUCH_ITEM(a);
           }
         }
+      }
+      if (n_words) {    // queries dirty in a single word of the group, listed word by word: { ~qI & constMask, ~qV, LDS offset, 0 } -- 6 VALU each
+        const uint32_t rE[4] = {pE.x, pE.y, pE.z, pE.w}, rV[4] = {pV.x, pV.y, pV.z, pV.w};
+#define WORD_ITEMS(J)                                                                                                             \
+        _Pragma("unroll 1") for (uint32_t k = (n_words >> (5 * J)) & 31u; k > 0; k--, sp += 4) {                                  \
+          QWords<3> it;                                                                                                           \
+          load_qwords(it, sp);                                                                                                    \
+          LDS_ADD(it.v[2], (uint32_t)bcnt_acc(rE[J] & it.v[0], 0) | ((uint32_t)bcnt_acc(rV[J] & it.v[1], 0) << 16));             \
+        }
+        WORD_ITEMS(0) WORD_ITEMS(1) WORD_ITEMS(2) WORD_ITEMS(3)
+#undef WORD_ITEMS
       }
     }
 #undef LDS_ADD
@@ -2006,16 +2019,37 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
           if ((fx | fy) == 0u) continue;
           const uint32_t fa = (fx | (fx >> 16)) & 0xFFFFu;
+          // a dirty query whose non-ACGT / invalid sites of this group all lie in ONE 32-column word (an isolated N or ambiguity
+          // code: more than half of the partially dirty cases) gets a 4-dword "word item" instead of the 12-dword general one
+          uint32_t f4 = 0, f1 = 0;
+          for (uint32_t m = fa; m; m &= m - 1) {
+            const int q = __builtin_ctz(m);
+            const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
+            int words = 0;
+            for (int j = 0; j < 4; j++) words += (src[j] | src[4 + j]) != 0u;
+            if (words == 1) f1 |= 1u << q; else f4 |= 1u << q;
+          }
+          uint32_t nw[4] = {0, 0, 0, 0};                // word items per word of the group, listed word by word
+          auto word_of = [&](int q) { const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8; int j = 0; while (!(src[j] | src[4 + j])) j++; return j; };
+          for (uint32_t m = f1; m; m &= m - 1) nw[word_of(__builtin_ctz(m))]++;
           strm.push_back((uint32_t)g * 2048u | ((fx & 0xFFFFu) ? 1u : 0u) | ((fx >> 16) ? 2u : 0u));
-          strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u); strm.push_back((uint32_t)__builtin_popcount(fa)); strm.push_back((uint32_t)g * 256u);
+          strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u | nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19);
+          strm.push_back((uint32_t)__builtin_popcount(f4)); strm.push_back((uint32_t)g * 256u);
           for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * 256u);
           while (strm.size() & 3) strm.push_back(16u * 256u);                                  // scratch row
-          for (uint32_t m = fa; m; m &= m - 1) {
+          for (uint32_t m = f4; m; m &= m - 1) {
             const int q = __builtin_ctz(m);
             const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
             strm.insert(strm.end(), src, src + 8);
             strm.push_back((uint32_t)q * 256u); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
           }
+          for (int j = 0; j < 4; j++)
+            for (uint32_t m = f1; m; m &= m - 1) {
+              const int q = __builtin_ctz(m);
+              if (word_of(q) != j) continue;
+              const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
+              strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)q * 256u); strm.push_back(0u);
+            }
           nrec++;
         }
         sdir[(size_t)t * 2 + 1] = nrec;

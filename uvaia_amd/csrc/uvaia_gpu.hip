@@ -748,7 +748,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const uint32_t h0 = h.v[0], n_full4 = h.v[1] & 15u, n_words = h.v[1] >> 4, n_gen = h.v[2];
       sp += 4;
       const char *tg = reinterpret_cast<const char *>(t) + (h0 & ~1023u);            // E plane of the group, V plane 1 KiB further
-      uint4 pE = make_uint4(0, 0, 0, 0), pV = pE;
+      // A plane that no item of the record needs is not loaded; its registers then hold whatever they held, which is harmless:
+      // every use is an AND with a mask word that is zero for such a plane.  (The empty asm only tells the compiler the
+      // registers are defined, so that it does not spend eight moves per record on zeroing them.)
+      uint4 pE, pV;
+      asm volatile("" : "=v"(pE.x), "=v"(pE.y), "=v"(pE.z), "=v"(pE.w), "=v"(pV.x), "=v"(pV.y), "=v"(pV.z), "=v"(pV.w));
       if (h0 & 1u) pE = *reinterpret_cast<const uint4 *>(tg);
       if (h0 & 2u) pV = *reinterpret_cast<const uint4 *>(tg + 1024);
       if (n_full4) {    // all-N queries: what they take away is the reference's own count for the group (same packing as the counters)

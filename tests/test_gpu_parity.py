@@ -215,6 +215,34 @@ def test_query_shards_equal_one_context(synth, acgt, gappy):
             e.close()
 
 
+@pytest.mark.parametrize("rare_max", ["1", "3", "40"])
+@pytest.mark.parametrize("acgt,trim", [(False, 0), (True, 0), (False, 230), (True, 230)])
+def test_rare_column_path_matches_oracle(synth, monkeypatch, acgt, trim, rare_max):
+    """Columns where all but a few queries carry the same base are scanned as constant columns plus sparse items (and, with
+    --acgt, dist_unique takes its rare-column part on demand).  The engine only does that for >= 64 queries; forced here on the
+    40-query set, from 'singletons only' to 'every polymorphic column is rare'.  Streaming and resident paths, bundled data too."""
+    monkeypatch.setenv("UVAIA_GPU_RARE_MAX", rare_max)
+    refs, qs = synth
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt, trim=trim)
+    _assert_same_search(q, refs, 100, 7)
+    rows_s, T_s, ent_s = _gpu_search(q, refs, 100, 7)
+    with capi.Engine.from_query(q, nbest=7, max_pool=512) as eng:
+        eng.db_append(refs)
+        ent = eng.search_resident(100)
+        n, T, sc, od = eng.drain()
+        assert capi.finalise_heaps(n, sc, od) == rows_s and list(T) == T_s and np.array_equal(ent, ent_s)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_rare_column_path_on_bundled_alignment(bundled_db, monkeypatch, acgt):
+    monkeypatch.setenv("UVAIA_GPU_RARE_MAX", "2")
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:24]
+    q = O.Query([by[n] for n in qn], qn, acgt=acgt)
+    _assert_same_search(q, seqs[:1500], 512, 5)
+
+
 def test_query_tile_sizes_agree(synth):
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"))

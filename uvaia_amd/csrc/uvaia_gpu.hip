@@ -89,8 +89,11 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][L,H,I,-][4]   compressed polymorphic columns of the queries
   uint32_t *d_stream = nullptr;  // per query tile: the dirty-word item stream of scan3_kernel (layout: see the kernel)
   uint2 *d_sdir = nullptr;       // [nq_pad/16] {first dword of the tile's stream, number of group records}
-  int NP = 0, NP4 = 0;
-  int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
+  int NP = 0, NP4 = 0;           // polymorphic columns counted densely
+  int NR = 0, NR4 = 0, rare_max = -1;   // "rare" columns: all but <= rare_max queries carry the same base; sparse (items), groups follow the dense ones
+  uint32_t *d_rmask = nullptr;   // [W4*4] mask of the rare columns
+  uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
+  int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
   int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
@@ -597,15 +600,16 @@ __global__ __launch_bounds__(256) void derive_ev_kernel(const uint4 *__restrict_
 
 // one wave per tile: compresses the polymorphic columns (uniform masks) of each lane's reference into NPw contiguous words
 // poly[tile][p4][plane L,H,I][lane] (uint4 = 4 consecutive compressed words)
+// mask[w * mstride]: the columns of word w to gather; they land in groups g0, g0+1, ... of the tile's NG groups
 template <bool ACGT>
-__global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict__ tiles, long long tile_base, int W4, int NP4,
-                                                          const uint32_t *__restrict__ cls, uint4 *__restrict__ poly)
+__global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict__ tiles, long long tile_base, int W4, int NG, int g0,
+                                                          const uint32_t *__restrict__ mask, int mstride, uint4 *__restrict__ poly)
 {
   constexpr int P = ACGT ? 3 : 4;
   const int lane = threadIdx.x;
   const long long tile = tile_base + blockIdx.x;
   const uint4 *t = tiles + (size_t)tile * W4 * P * 64 + lane;
-  uint4 *o = poly + (size_t)tile * NP4 * 3 * 64 + lane;
+  uint4 *o = poly + ((size_t)tile * NG + g0) * 3 * 64 + lane;
   unsigned long long bL = 0, bH = 0, bI = 0;     // bit staging (uniform fill level)
   int fill = 0, ow = 0;                          // bits staged, compressed words emitted
   uint32_t wL[4] = {0, 0, 0, 0}, wH[4] = {0, 0, 0, 0}, wI[4] = {0, 0, 0, 0};
@@ -622,12 +626,12 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
     ow++;
   };
   for (int w4 = 0; w4 < W4; w4++) {
-    const uint32_t *c4 = cls + (size_t)w4 * 16;
-    if ((c4[3] | c4[7] | c4[11] | c4[15]) == 0u) continue;            // no polymorphic column in this group (uniform)
+    const uint32_t *c4 = mask + (size_t)w4 * 4 * mstride;
+    if ((c4[0] | c4[mstride] | c4[2 * mstride] | c4[3 * mstride]) == 0u) continue;   // no such column in this group (uniform)
     const uint4 p0 = t[(size_t)(w4 * P + 0) * 64], p1 = t[(size_t)(w4 * P + 1) * 64], p2 = t[(size_t)(w4 * P + 2) * 64], p3 = t[(size_t)(w4 * P + (P - 1)) * 64];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      uint32_t m = c4[j * 4 + 3];
+      uint32_t m = c4[j * mstride];
       if (!m) continue;
       uint32_t rL, rH, rI;
       if (ACGT) { rL = u4c(p0, j); rH = u4c(p1, j); rI = u4c(p2, j); }
@@ -659,22 +663,25 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 //     validity deficit << 16) live in LDS and take one ds_add_u32 per item, and a query that is N/gap over a whole 128-column
 //     group costs a single ds_add of the reference's own per-group counts (grp[]).
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
-// stream (dwords), per query tile, sdir[qtile] = {first dword, number of group records}:
+// stream (dwords), per query tile, sdir[qtile] = {first dword, number of group records | number of rare records << 16}:
 //   record = { w4 * 2048 (byte offset of the group's E plane in the tile) | needE | needV << 1,  n_full4 = ceil(n_full / 4),  n_generic,
 //              w4 * 256 (byte offset of the group's grp[] row) }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
 //            + n_generic x { ~qI & constMask [4],  ~qV (default) / ~qI (--acgt) [4],  LDS offset, 0, 0, 0 }
 //            + word items { ~qI & constMask, ~qV, LDS offset, 0 } of the queries that are dirty in ONE word of the group only, listed word
 //              by word; their four counts sit in bits 4.. of the second header word (5 bits each)
+//   rare record (after the group records) = { byte offset of a rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }
+//            + items { sites, their lo bits, their hi bits, LDS offset }, word by word
 // qpl[q][p4][L,H,I,-][4]: compressed planes of the polymorphic columns
 template <int QT, bool ACGT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
-                                                     int W4, int NP4, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ stream,
+                                                     int W4, int NP4, int NPT, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ stream,
                                                      const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
                                                      const int *__restrict__ tot_e, const int *__restrict__ tot_v,
                                                      int2 *__restrict__ out, int ppad, int n_qtiles, int2 *__restrict__ tmin, int r_lo, int r_hi,
                                                      int *__restrict__ mp_out, int parts, int qtile_first)
 {
   static_assert(QT == 16, "stream offsets are laid out for tiles of 16 queries");
+  constexpr uint32_t RARE_BIAS = 8192u;                      // the low counter half also takes what rare items give back: keep it positive
   __shared__ uint32_t lacc[4][QT + 1][64];                     // per wave: one packed counter per (query, lane) + a scratch row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int qtile, group;
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int q = 0; q < QT; q++) acc[q] = 0;
     // ---- polymorphic columns, dense
     if (parts & 1) {
-      const uint4 *t = poly + (size_t)(tile_first + trel) * NP4 * 3 * 64 + lane;
+      const uint4 *t = poly + (size_t)(tile_first + trel) * NPT * 3 * 64 + lane;
       const size_t qstride = (size_t)NP4 * 16;
       const uint32_t *qb = qpl + (size_t)q0 * qstride;
       for (int p4 = 0; p4 < NP4; p4++) {
@@ -720,8 +727,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 #pragma unroll
     for (int q = 0; q < QT; q++) {
-      if (ACGT) { mp_out[(size_t)(q0 + q) * ppad + r] = acc[q]; my[q * 64] = 0u; }
-      else my[q * 64] = (uint32_t)acc[q];
+      if (ACGT) { mp_out[(size_t)(q0 + q) * ppad + r] = acc[q]; my[q * 64] = RARE_BIAS; }
+      else my[q * 64] = (uint32_t)acc[q] + RARE_BIAS;
     }
   }
   // ---- constant columns and validity: the item stream of this query tile
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       LDS_ADD(it.v[8], (uint32_t)e_ | ((uint32_t)v_ << 16));                                                        \
     }
 #define TOUCH_ITEM(it) asm volatile("" ::"s"(it.v[0]), "s"(it.v[1]), "s"(it.v[2]), "s"(it.v[3]), "s"(it.v[4]), "s"(it.v[5]), "s"(it.v[6]), "s"(it.v[7]), "s"(it.v[8]))
-    for (uint32_t rec = 0; rec < dir.y; rec++) {
+    for (uint32_t rec = 0; rec < (dir.y & 0xFFFFu); rec++) {
       QWords<4> h;
       load_qwords(h, sp);
       const uint32_t h0 = h.v[0], n_full4 = h.v[1] & 15u, n_words = h.v[1] >> 4, n_gen = h.v[2];
@@ -800,6 +807,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #undef WORD_ITEMS
       }
     }
+    // ---- rare columns: the queries that do not carry a rare column's majority base were made dirty there above (their E bit is
+    // taken away); here they get the true comparison on the gathered planes of the rare columns, as a negative deficit
+    {
+      const char *tr = reinterpret_cast<const char *>(poly + (size_t)(tile_first + trel) * NPT * 3 * 64 + lane);
+      for (uint32_t rec = 0; rec < (dir.y >> 16); rec++) {
+        QWords<2> h;
+        load_qwords(h, sp);
+        sp += 4;
+        const uint4 pL = *reinterpret_cast<const uint4 *>(tr + h.v[0]), pH = *reinterpret_cast<const uint4 *>(tr + h.v[0] + 1024),
+                    pI = *reinterpret_cast<const uint4 *>(tr + h.v[0] + 2048);
+        const uint32_t rL[4] = {pL.x, pL.y, pL.z, pL.w}, rH[4] = {pH.x, pH.y, pH.z, pH.w}, rI[4] = {pI.x, pI.y, pI.z, pI.w};
+        const uint32_t n_words = h.v[1] >> 4;
+#define RARE_ITEMS(J)                                                                                                             \
+        _Pragma("unroll 1") for (uint32_t k = (n_words >> (5 * J)) & 31u; k > 0; k--, sp += 4) {                                  \
+          QWords<4> it;                                         /* sites, their lo bits, their hi bits, LDS offset */             \
+          load_qwords(it, sp);                                                                                                    \
+          const uint32_t d_ = rL[J] ^ it.v[1];                                                                                    \
+          const uint32_t y_ = B3(rH[J], it.v[2], d_, (TT_A ^ TT_B) | TT_C);                                                       \
+          const uint32_t g_ = ACGT ? B3(y_, rI[J], it.v[0], TT_A & TT_B & TT_C) : B3(y_, rI[J], it.v[0], ~TT_A & TT_B & TT_C);   \
+          LDS_ADD(it.v[3], 0u - (uint32_t)bcnt_acc(g_, 0));     /* matches (default) / mismatches (--acgt) found: deficit goes down */ \
+        }
+        RARE_ITEMS(0) RARE_ITEMS(1) RARE_ITEMS(2) RARE_ITEMS(3)
+#undef RARE_ITEMS
+      }
+    }
 #undef LDS_ADD
 #undef COUNT_ITEM
 #undef TOUCH_ITEM
@@ -811,7 +843,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
   for (int q = 0; q < QT; q++) {
     const uint32_t pk = my[q * 64];
-    const int c0 = (ACGT ? mp_in[(size_t)(q0 + q) * ppad + r] + te : te + NP4 * 128) - (int)(pk & 0xFFFFu), c1 = tv - (int)(pk >> 16);
+    const int c0 = (ACGT ? mp_in[(size_t)(q0 + q) * ppad + r] + te : te + NP4 * 128) - ((int)(pk & 0xFFFFu) - (int)RARE_BIAS), c1 = tv - (int)(pk >> 16);
     out[(size_t)(q0 + q) * ppad + r] = make_int2(c0, c1);
     // Two bounds per tile let the replay skip tiles that cannot admit anything: the smallest mismatch count (the gate of
     // src/nearest.c:488 needs mismatches < tolerance) and the largest ACGT-match count (a full heap only takes a key that is not
@@ -1336,6 +1368,22 @@ static __device__ int wave_acgt_poly_mismatches(const uint4 *__restrict__ db, si
   return wave_sum(mp);
 }
 
+// --acgt with rare columns: the scan's dense count covers the truly polymorphic columns only; the mismatches of one pair on the
+// rare columns (which belong to dist_unique as well) are counted here on the gathered planes: NR4 * 4 words, one per lane.
+static __device__ int wave_rare_mismatches(const uint4 *__restrict__ polyp, size_t tile_abs, int lane_r, int NPT, int NP4, int NR4,
+                                           const uint32_t *__restrict__ qr /* [NR4 * 4][lo, hi, isACGT] */, int lane)
+{
+  const uint32_t *pw = reinterpret_cast<const uint32_t *>(polyp);
+  int mp = 0;
+  for (int w = lane; w < NR4 * 4; w += 64) {
+    const size_t base = (((size_t)tile_abs * NPT + NP4 + (w >> 2)) * 3) * 256 + (size_t)lane_r * 4 + (w & 3);
+    const uint32_t rL = pw[base], rH = pw[base + 256], rI = pw[base + 512];
+    const uint32_t *s_ = qr + (size_t)w * 3;
+    mp += __popc(((rL ^ s_[0]) | (rH ^ s_[1])) & rI & s_[2]);
+  }
+  return wave_sum_dpp(mp);
+}
+
 // Replay over the two-counter scan.  One wave per query walks the batch in reference order, 256 references per
 // round.  Between two admissions the heap state is constant, so the exact tests of src/nearest.c:488-496 and
 // src/min_heap.c:95 are evaluated for 64 references at once (ballot); the first survivor in order gets its missing
@@ -1350,7 +1398,8 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
                                                       const uint4 *__restrict__ db, long long tile_first, int W4,
                                                       const uint32_t *__restrict__ qfull, const int *__restrict__ amb_q,
                                                       unsigned long long *__restrict__ stats, int q_first, const int2 *__restrict__ tmin,
-                                                      const int *__restrict__ mpbuf, int lq_words, int prio_)
+                                                      const int *__restrict__ mpbuf, int lq_words, int prio_,
+                                                      const uint4 *__restrict__ polyp, int NPT, int NP4, int NR4, const uint32_t *__restrict__ qrare)
 {
   extern __shared__ int h[];
   if (prio_) __builtin_amdgcn_s_setprio(3);     // few latency-bound waves on the critical path: win issue arbitration against co-resident scan waves
@@ -1517,7 +1566,8 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
           n_demand++;
           if (ACGT) {
             // with the column-compressed scan the dense count on the polymorphic columns IS score[5] (src/nearest.c:469)
-            const int mp = mpbuf ? cur.row : wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
+            int mp = mpbuf ? cur.row : wave_acgt_poly_mismatches(db, tile_abs, rl & 63, W4, qrow, lane);
+            if (mpbuf && NR4 > 0) mp += wave_rare_mismatches(polyp, tile_abs, rl & 63, NPT, NP4, NR4, qrare + (size_t)q * NR4 * 12, lane);
             assemble_scores<true>(make_int4(cx, cy, mp, 0), ai, ri, nni, Si, mi);
           } else {
             bool dense;
@@ -1699,8 +1749,8 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
+    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
+    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1774,7 +1824,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
                                     c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int2 *)nullptr, \
-                                    c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio)
+                                    c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1797,10 +1847,12 @@ int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref)
   const int nblk = (int)(t1 - t0 + 1);
   if (c->acgt) {
     hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
+    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
+    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
   } else {
     hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4, c->d_cls, poly);
+    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
+    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
   }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -1853,7 +1905,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
@@ -1973,13 +2025,49 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           cL |= qL & fresh; cH |= qH & fresh; seen |= qI;
         }
         cls[(size_t)w * 4 + 0] = cL & ~poly; cls[(size_t)w * 4 + 1] = cH & ~poly; cls[(size_t)w * 4 + 2] = seen & ~poly; cls[(size_t)w * 4 + 3] = poly;
-        c->NP += __builtin_popcount(poly);
       }
+      // Rare columns: polymorphic, but all except a few queries carry the same base (private mutations, sequencing noise: 95 % of
+      // the polymorphic columns of the benchmark queries).  They are handled like constant columns with that base; the few
+      // queries that differ are "dirty" there (their E bit is taken away by the usual items) and get the true comparison from a
+      // sparse item on the gathered planes of the rare columns.  Dense work remains for the truly polymorphic columns only.
+      std::vector<uint32_t> rmask((size_t)Wp, 0u);
+      {
+        const char *er = getenv("UVAIA_GPU_RARE_MAX");
+        c->rare_max = er ? atoi(er) : (c->nq < 64 ? 0 : std::min(64, std::max(4, c->nq / 64)));
+        if (c->fullscan || c->scan_variant != 2) c->rare_max = 0;
+      }
+      if (c->rare_max > 0) {
+        std::vector<int> cnt(32 * 4);
+        for (int w = 0; w < Wp; w++) {
+          const uint32_t pm = cls[(size_t)w * 4 + 3];
+          if (!pm) continue;
+          std::fill(cnt.begin(), cnt.end(), 0);
+          for (int i = 0; i < c->nq; i++) {
+            const uint32_t qL = QL(i, w, 0), qH = QL(i, w, 1);
+            for (uint32_t m = QL(i, w, 2) & pm; m; m &= m - 1) { const int b = __builtin_ctz(m); cnt[(size_t)b * 4 + (((qL >> b) & 1u) | (((qH >> b) & 1u) << 1))]++; }
+          }
+          for (uint32_t m = pm; m; m &= m - 1) {
+            const int b = __builtin_ctz(m);
+            int major = 0, total = 0;
+            for (int k = 0; k < 4; k++) { total += cnt[(size_t)b * 4 + k]; if (cnt[(size_t)b * 4 + k] > cnt[(size_t)b * 4 + major]) major = k; }
+            if (total - cnt[(size_t)b * 4 + major] > c->rare_max) continue;
+            const uint32_t bit = 1u << b;
+            cls[(size_t)w * 4 + 0] = (cls[(size_t)w * 4 + 0] & ~bit) | ((major & 1) ? bit : 0u);
+            cls[(size_t)w * 4 + 1] = (cls[(size_t)w * 4 + 1] & ~bit) | ((major & 2) ? bit : 0u);
+            cls[(size_t)w * 4 + 2] |= bit; cls[(size_t)w * 4 + 3] &= ~bit; rmask[(size_t)w] |= bit;
+          }
+        }
+      }
+      for (int w = 0; w < Wp; w++) { c->NP += __builtin_popcount(cls[(size_t)w * 4 + 3]); c->NR += __builtin_popcount(rmask[(size_t)w]); }
       c->NP4 = ((c->NP + 31) / 32 + 3) / 4;
+      c->NR4 = ((c->NR + 31) / 32 + 3) / 4;
+      struct RareWord { int word; uint32_t m, l, h; };                  // one query's minority sites in one compressed word of the rare columns
+      std::vector<std::vector<RareWord>> rare_q((size_t)c->nq_pad);
+      std::vector<uint32_t> qrare((size_t)c->nq * std::max(c->NR4, 1) * 12, 0u);
       const size_t prow = (size_t)std::max(c->NP4, 1) * 16, crow = (size_t)c->W4 * 8;
       std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4 * 2, 0u);
       for (int i = 0; i < c->nq_pad; i++) {
-        int k = 0;                                                   // compressed bit position
+        int k = 0, kr = 0;                                           // compressed bit position among the dense / the rare columns
         bool full = false;                                           // all 128 columns of the current word group are N/gap
         for (int w = 0; w < Wp; w++) {
           const bool real = i < c->nq;
@@ -1989,7 +2077,18 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
             uint32_t *d = qpl.data() + (size_t)i * prow + (size_t)(k >> 7) * 16 + ((k >> 5) & 3);     // [p4][L,H,I,-][word of the group]
             d[0] |= ((qL >> b) & 1u) << (k & 31); d[4] |= ((qH >> b) & 1u) << (k & 31); d[8] |= ((qI >> b) & 1u) << (k & 31);
           }
-          const uint32_t nI = ~qI & cls[(size_t)w * 4 + 2], nV = ~qV;
+          // dirty on a constant (or rare) column = not carrying the column's base there
+          const uint32_t eqb = qI & ~((qL ^ cls[(size_t)w * 4 + 0]) | (qH ^ cls[(size_t)w * 4 + 1]));
+          const uint32_t nI = ~eqb & cls[(size_t)w * 4 + 2], nV = ~qV;
+          for (uint32_t m = rmask[(size_t)w]; m; m &= m - 1, kr++) {
+            const int b = __builtin_ctz(m);
+            if (real) { uint32_t *d = qrare.data() + ((size_t)i * c->NR4 * 4 + (size_t)(kr >> 5)) * 3;
+                        d[0] |= ((qL >> b) & 1u) << (kr & 31); d[1] |= ((qH >> b) & 1u) << (kr & 31); d[2] |= ((qI >> b) & 1u) << (kr & 31); }
+            if (!real || !((qI >> b) & 1u) || ((eqb >> b) & 1u)) continue;          // only ACGT queries that differ from the majority
+            if (rare_q[(size_t)i].empty() || rare_q[(size_t)i].back().word != (kr >> 5)) rare_q[(size_t)i].push_back({kr >> 5, 0u, 0u, 0u});
+            RareWord &rw = rare_q[(size_t)i].back();
+            rw.m |= 1u << (kr & 31); rw.l |= ((qL >> b) & 1u) << (kr & 31); rw.h |= ((qH >> b) & 1u) << (kr & 31);
+          }
           qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + (w & 3)] = nI; qcv[(size_t)i * crow + (size_t)(w >> 2) * 8 + 4 + (w & 3)] = nV;
           uint32_t *fw = &flg[((size_t)(i / 16) * c->W4 + (w >> 2)) * 2];
           if (real && nI) fw[0] |= 1u << (i % 16);       // padding queries of the last tile are never read back: keep them "clean"
@@ -2013,9 +2112,12 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
       if (c->replay_lq < 0) c->replay_lq = (c->nq < 256) ? 1 : 0;
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
+      OPENCHK(hipMalloc(&c->d_qrare, qrare.size() * 4)); OPENCHK(hipMemcpy(c->d_qrare, qrare.data(), qrare.size() * 4, hipMemcpyHostToDevice));
+      OPENCHK(hipMalloc(&c->d_rmask, rmask.size() * 4)); OPENCHK(hipMemcpy(c->d_rmask, rmask.data(), rmask.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
       std::vector<uint32_t> strm, sdir((size_t)(c->nq_pad / 16) * 2, 0u);
+      std::vector<uint8_t> rare_groups_needed((size_t)std::max(c->NR4, 1), 0);
       for (int t = 0; t < c->nq_pad / 16; t++) {
         sdir[(size_t)t * 2] = (uint32_t)strm.size();
         uint32_t nrec = 0;
@@ -2056,8 +2158,23 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
             }
           nrec++;
         }
-        sdir[(size_t)t * 2 + 1] = nrec;
+        // rare records: { byte offset of the rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }
+        // + items { sites, their lo bits, their hi bits, LDS offset } listed word by word
+        uint32_t nrare = 0;
+        for (int r4 = 0; r4 < c->NR4; r4++) {
+          uint32_t nw[4] = {0, 0, 0, 0};
+          for (int q = 0; q < 16; q++) for (const RareWord &rw : rare_q[(size_t)t * 16 + q]) if ((rw.word >> 2) == r4) nw[rw.word & 3]++;
+          if (!(nw[0] | nw[1] | nw[2] | nw[3])) continue;
+          strm.push_back((uint32_t)(c->NP4 + r4) * 3072u); strm.push_back(nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19); strm.push_back(0u); strm.push_back(0u);
+          for (int j = 0; j < 4; j++)
+            for (int q = 0; q < 16; q++) for (const RareWord &rw : rare_q[(size_t)t * 16 + q]) if (rw.word == r4 * 4 + j) {
+              strm.push_back(rw.m); strm.push_back(rw.l); strm.push_back(rw.h); strm.push_back((uint32_t)q * 256u);
+            }
+          nrare++; rare_groups_needed[(size_t)r4] = 1;
+        }
+        sdir[(size_t)t * 2 + 1] = nrec | (nrare << 16);
       }
+      for (uint8_t u : rare_groups_needed) c->need_r_groups += u;
       strm.resize(strm.size() + 64, 0u);                                // the kernel prefetches one item past the end
       OPENCHK(hipMalloc(&c->d_stream, strm.size() * 4)); OPENCHK(hipMemcpy(c->d_stream, strm.data(), strm.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_sdir, sdir.size() * 4)); OPENCHK(hipMemcpy(c->d_sdir, sdir.data(), sdir.size() * 4, hipMemcpyHostToDevice));
@@ -2086,7 +2203,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_ev, (c->pool_pad / 64) * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
   OPENCHK(hipMalloc(&c->d_batch_grp, (c->pool_pad / 64) * (size_t)c->W4 * 64 * sizeof(uint32_t)));
-  OPENCHK(hipMalloc(&c->d_batch_poly, (c->pool_pad / 64) * (size_t)std::max(c->NP4, 1) * 3 * 64 * sizeof(uint4)));
+  OPENCHK(hipMalloc(&c->d_batch_poly, (c->pool_pad / 64) * (size_t)std::max(c->NP4 + c->NR4, 1) * 3 * 64 * sizeof(uint4)));
   OPENCHK(hipMalloc(&c->d_batch_tote, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
@@ -2144,7 +2261,7 @@ size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
   // some query tile needs (groups where every query is clean are never loaded) + three planes of the gathered polymorphic columns
   if (!c) return 0;
   return (c->fullscan || c->scan_variant != 2) ? (size_t)c->W4 * 16 * c->P
-                                                : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->need_g_groups * 4 + (size_t)c->NP4 * 16 * 3;
+                                                : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->need_g_groups * 4 + (size_t)(c->NP4 + c->need_r_groups) * 16 * 3;
 }
 
 int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
@@ -2205,7 +2322,7 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_ev, tiles * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_grp, tiles * (size_t)c->W4 * 64 * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&c->d_db_poly, tiles * (size_t)std::max(c->NP4, 1) * 3 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_poly, tiles * (size_t)std::max(c->NP4 + c->NR4, 1) * 3 * 64 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_tote, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_tot, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_tot, 0, tiles * 64 * sizeof(int)));
@@ -2545,7 +2662,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int2 *)nullptr, \
-                                  c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio)
+                                  c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2

@@ -243,6 +243,18 @@ def test_rare_column_path_on_bundled_alignment(bundled_db, monkeypatch, acgt):
     _assert_same_search(q, seqs[:1500], 512, 5)
 
 
+@pytest.mark.parametrize("nchar,nq,nref,seed", [(777, 80, 500, 5), (129, 70, 300, 6), (2047, 130, 400, 7)])
+@pytest.mark.parametrize("acgt", [False, True])
+def test_odd_shapes_with_enough_queries_for_every_path(acgt, nchar, nq, nref, seed):
+    """Alignment lengths that are not multiples of 32 or 128, query counts that are not multiples of 16 and large enough (>= 64)
+    for the rare-column path to switch itself on: streaming with two pool sizes against the oracle."""
+    refs, root, cols = F.synth_alignment(nref, nchar, seed=seed)
+    qs, _, _ = F.synth_alignment(nq, nchar, seed=seed + 100, root=root, poly_cols=cols)
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+    _assert_same_search(q, refs, 97, 6)
+    _assert_same_search(q, refs, nref, 3)
+
+
 def test_query_tile_sizes_agree(synth):
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"))

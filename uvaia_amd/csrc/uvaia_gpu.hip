@@ -95,6 +95,8 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
+  bool serial = false;           // UVAIA_GPU_SERIAL: no scan/replay overlap (to time the kernels in isolation)
+  int subslice_minq = 256;       // sub-slicing of pools only from this many active queries (UVAIA_GPU_SUBSLICE_MINQ)
   int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
@@ -2108,6 +2110,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       { const char *ep = getenv("UVAIA_GPU_REPLAY_PRIO"); if (ep) c->replay_prio = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_SCAN_LDS_PAD"); if (ep) c->scan_lds_pad = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_REPLAY_LQ"); if (ep) c->replay_lq = atoi(ep); }
+      { const char *ep = getenv("UVAIA_GPU_SUBSLICE_MINQ"); if (ep) c->subslice_minq = atoi(ep); }
+      c->serial = getenv("UVAIA_GPU_SERIAL") != nullptr;
       // Next to a running scan (8 blocks x 16.9 KB of LDS per CU) a replay block with the 22 KB query row fits once per CU, without
       // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
       if (c->replay_lq < 0) c->replay_lq = (c->nq < 256) ? 1 : 0;
@@ -2442,11 +2446,10 @@ static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first
   std::vector<SubSlice> subs;
   // with few queries the replay is negligible and small launches only cost: one slice per pool then.  The sub-slice length is
   // tuned for 63 query tiles (1 000 queries); with fewer active tiles (query shards) it grows so that a launch still fills the chip
-  const char *env_minq = getenv("UVAIA_GPU_SUBSLICE_MINQ");
   const int nq_act = c->act_q1 - c->act_q0, nqt = (c->act_q1 + 15) / 16 - c->act_q0 / 16;
   size_t sub = c->subslice;
   if (nqt < 63) sub = std::min(pool, (sub * 63 / (size_t)std::max(nqt, 1) + 63) / 64 * 64);
-  if (nq_act < (env_minq ? atoi(env_minq) : 256)) sub = pool;
+  if (nq_act < c->subslice_minq) sub = pool;
   for (size_t a = first; a < first + n; a += pool) {
     const size_t pe = std::min(first + n, a + pool);
     // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
@@ -2465,7 +2468,7 @@ static int run_subslices(uvaia_gpu_ctx *c, const std::vector<SubSlice> &subs, in
   const size_t ns = subs.size();
   size_t issued = 0;
   for (size_t i = 0; i < ns; i++) {
-    const bool serial_ = getenv("UVAIA_GPU_SERIAL") != nullptr;
+    const bool serial_ = c->serial;
     while (issued < ns && issued < i + (serial_ ? 1 : NBUF)) {          // keep the scan stream fed
       int rc = uvaia_gpu_slice_scan(c, subs[issued].first, subs[issued].n, (int)(issued % NBUF));
       if (rc) return rc;

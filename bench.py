@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--multi", choices=["shards", "ring"], default="shards",
                     help="N > 1: 'shards' = every GPU holds the whole database and a range of the queries (no data-path exchange); "
                          "'ring' = every GPU holds 1/N of the database, heap state handed rank to rank (uvaia_amd/ring.py)")
+    ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N",
+                    help="single process: do the work of rank 0 of N query shards (whole stream of N x --refs references, 1/N of the queries) "
+                         "to measure the per-rank time of an N-GPU run on one GPU; the line is marked as emulated")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
     return ap.parse_args()
 
@@ -87,8 +90,9 @@ def main():
     t_q0 = time.time()
     pq = hostlib.PreparedQuery(qseqs, qnames, acgt=(args.mode == "acgt"))
     t_q1 = time.time()
-    shard_mode = world > 1 and args.multi == "shards"
-    local_refs = world * args.refs if shard_mode else args.refs      # query shards: every rank holds (and scans) the whole stream
+    emu = args.emulate_shard_of if (world == 1 and args.emulate_shard_of > 1) else 0
+    shard_mode = (world > 1 and args.multi == "shards") or emu > 0
+    local_refs = (emu or world) * args.refs if shard_mode else args.refs      # query shards: every rank holds (and scans) the whole stream
     pool = min(args.pool, local_refs)
     eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank)
     t_q2 = time.time()
@@ -113,13 +117,13 @@ def main():
     comm = ring.TorchRingComm(dist, rank, world, cuda=on_gpu) if (dist is not None and not shard_mode) else None
     nbytes = eng.state_bytes()
     cons = len(pq.idx_c) > 0
-    q0, q1 = shards.query_shard(pq.ntax, rank, world) if shard_mode else (0, pq.ntax)
-    allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons) else None
+    q0, q1 = shards.query_shard(pq.ntax, rank, emu or world) if shard_mode else (0, pq.ntax)
+    allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons and dist is not None) else None
 
     # ---- timed region
     def step():
         eng.reset()
-        if world == 1:
+        if world == 1 and not emu:
             eng.search_resident(pool, ordinal0=0, want_entered=False)
         elif shard_mode:   # no data-path exchange (one all-reduced int per pool if the query set has complete constant columns)
             shards.run_query_shard(eng, q0, q1, local_refs, pool, cons, allmax)
@@ -144,7 +148,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
-    value = world * args.refs * args.steps / elapsed
+    value = (emu or world) * args.refs * args.steps / elapsed
 
     # ---- roofline of the dominant kernel (pair scan): algorithmic bytes per launch / mean launch time (HIP events)
     launches = max(1, scan_launches)
@@ -207,7 +211,7 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle's restatement of the reference loops on a bounded sample
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and args.cpu_refs > 0:
+    if rank == 0 and world == 1 and not emu and args.cpu_refs > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         n_s = min(args.cpu_refs, args.refs)
@@ -255,7 +259,8 @@ def main():
             "metric": "ref-seqs scored/sec", "value": round(value, 2), "unit": "ref-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "multi_gpu": None if world == 1 else
+            "emulated": ("rank 0 of %d query shards on one GPU: `value` is what %d GPUs would reach if every rank took this long" % (emu, emu)) if emu else None,
+            "multi_gpu": None if (world == 1 and not emu) else
             ("query shards: every GPU holds all %d references and the heaps of %d of the %d queries (column classes from the whole set); no data-path exchange%s; exact"
              % (local_refs, q1 - q0, pq.ntax, ", one all-reduced int per pool" if cons else "")) if shard_mode else
             "block-cyclic slices of %d refs, concurrent scans, heap state (%d B in %d per-query-group blobs) pipelined rank to rank (RCCL isend/irecv), exact" % (pool, nbytes, world),

@@ -65,9 +65,13 @@ struct ScanEvt { hipEvent_t a, b; double bytes; };
 struct uvaia_gpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t scan_streams[3] = {};       // extra scan streams: small launches (few active query tiles) overlap on up to three streams
+  unsigned scan_rr = 0;
+  int scan_nstreams = 1;                  // streams consecutive scans alternate over (set per search from the launch size)
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
   hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
+  size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
   int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
   int2 *d_tmin[NBUF] = {};                // per (query, tile of 64 references): {smallest mismatch count, largest ACGT-match count}, one per counter buffer
   int *d_mp[NBUF] = {};                   // --acgt: mismatches on the polymorphic columns per pair (dist_unique), one per counter buffer
@@ -95,6 +99,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
+  int scan_pf = -1;              // UVAIA_GPU_SCAN_PF: force the plane prefetch of the scan on (1) / off (0); default by active query tiles
   bool serial = false;           // UVAIA_GPU_SERIAL: no scan/replay overlap (to time the kernels in isolation)
   int subslice_minq = 256;       // sub-slicing of pools only from this many active queries (UVAIA_GPU_SUBSLICE_MINQ)
   int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
@@ -667,14 +672,15 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
 // stream (dwords), per query tile, sdir[qtile] = {first dword, number of group records | number of rare records << 16}:
 //   record = { w4 * 2048 (byte offset of the group's E plane in the tile) | needE | needV << 1,  n_full4 = ceil(n_full / 4),  n_generic,
-//              w4 * 256 (byte offset of the group's grp[] row) }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
+//              first word of the NEXT record (0 after the last) }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
+//            (bit 2 of the first word: some query is all-N here, the group's grp[] row at byte offset w4 * 256 is needed)
 //            + n_generic x { ~qI & constMask [4],  ~qV (default) / ~qI (--acgt) [4],  LDS offset, 0, 0, 0 }
 //            + word items { ~qI & constMask, ~qV, LDS offset, 0 } of the queries that are dirty in ONE word of the group only, listed word
 //              by word; their four counts sit in bits 4.. of the second header word (5 bits each)
 //   rare record (after the group records) = { byte offset of a rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }
 //            + items { sites, their lo bits, their hi bits, LDS offset }, word by word
 // qpl[q][p4][L,H,I,-][4]: compressed planes of the polymorphic columns
-template <int QT, bool ACGT>
+template <int QT, bool ACGT, bool PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
                                                      int W4, int NP4, int NPT, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ stream,
                                                      const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
@@ -751,21 +757,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       LDS_ADD(it.v[8], (uint32_t)e_ | ((uint32_t)v_ << 16));                                                        \
     }
 #define TOUCH_ITEM(it) asm volatile("" ::"s"(it.v[0]), "s"(it.v[1]), "s"(it.v[2]), "s"(it.v[3]), "s"(it.v[4]), "s"(it.v[5]), "s"(it.v[6]), "s"(it.v[7]), "s"(it.v[8]))
+    // PF (few active query tiles: a reference's planes are no longer found in L2 by the later tiles, every record then waits a
+    // full HBM round trip): the planes of the NEXT record are requested before the current one is counted; its first header
+    // word travels in the current header.  A plane that no item of a record needs is not loaded; its registers then hold
+    // whatever they held, which is harmless: every use is an AND with a mask word that is zero for such a plane.  (The empty asm
+    // only tells the compiler the registers are defined, so that it does not spend moves on zeroing them.)
+    uint4 pE, pV, nE, nV;
+    uint32_t g = 0u, ng = 0u;
+    asm volatile("" : "=v"(pE.x), "=v"(pE.y), "=v"(pE.z), "=v"(pE.w), "=v"(pV.x), "=v"(pV.y), "=v"(pV.z), "=v"(pV.w));
+    asm volatile("" : "=v"(nE.x), "=v"(nE.y), "=v"(nE.z), "=v"(nE.w), "=v"(nV.x), "=v"(nV.y), "=v"(nV.z), "=v"(nV.w));
+    if (PF && (dir.y & 0xFFFFu)) {
+      const uint32_t hf = sp[0];
+      const char *tg = reinterpret_cast<const char *>(t) + (hf & ~1023u);
+      if (hf & 1u) nE = *reinterpret_cast<const uint4 *>(tg);
+      if (hf & 2u) nV = *reinterpret_cast<const uint4 *>(tg + 1024);
+      if (hf & 4u) ng = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + ((hf & ~1023u) >> 3));
+    }
     for (uint32_t rec = 0; rec < (dir.y & 0xFFFFu); rec++) {
       QWords<4> h;
       load_qwords(h, sp);
       const uint32_t h0 = h.v[0], n_full4 = h.v[1] & 15u, n_words = h.v[1] >> 4, n_gen = h.v[2];
       sp += 4;
-      const char *tg = reinterpret_cast<const char *>(t) + (h0 & ~1023u);            // E plane of the group, V plane 1 KiB further
-      // A plane that no item of the record needs is not loaded; its registers then hold whatever they held, which is harmless:
-      // every use is an AND with a mask word that is zero for such a plane.  (The empty asm only tells the compiler the
-      // registers are defined, so that it does not spend eight moves per record on zeroing them.)
-      uint4 pE, pV;
-      asm volatile("" : "=v"(pE.x), "=v"(pE.y), "=v"(pE.z), "=v"(pE.w), "=v"(pV.x), "=v"(pV.y), "=v"(pV.z), "=v"(pV.w));
-      if (h0 & 1u) pE = *reinterpret_cast<const uint4 *>(tg);
-      if (h0 & 2u) pV = *reinterpret_cast<const uint4 *>(tg + 1024);
+      if (PF) {
+        pE = nE; pV = nV; g = ng;
+        const uint32_t hn = h.v[3];                                                    // first header word of the next record (0 after the last)
+        const char *tn = reinterpret_cast<const char *>(t) + (hn & ~1023u);
+        if (hn & 1u) nE = *reinterpret_cast<const uint4 *>(tn);
+        if (hn & 2u) nV = *reinterpret_cast<const uint4 *>(tn + 1024);
+        if (hn & 4u) ng = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + ((hn & ~1023u) >> 3));
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        const char *tg = reinterpret_cast<const char *>(t) + (h0 & ~1023u);            // E plane of the group, V plane 1 KiB further
+        if (h0 & 1u) pE = *reinterpret_cast<const uint4 *>(tg);
+        if (h0 & 2u) pV = *reinterpret_cast<const uint4 *>(tg + 1024);
+        if (n_full4) g = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + ((h0 & ~1023u) >> 3));
+      }
       if (n_full4) {    // all-N queries: what they take away is the reference's own count for the group (same packing as the counters)
-        const uint32_t g = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + h.v[3]);
 #pragma unroll 1
         for (uint32_t k = 0; k < n_full4; k++, sp += 4) {      // four LDS offsets per step; the list is padded with a scratch row
           QWords<4> o;
@@ -1448,9 +1475,12 @@ __global__ __launch_bounds__(64) void replay2_kernel(const int2 *__restrict__ cn
   const int2 *tmrow = use_tmin ? tmin + (size_t)q * (ppad >> 6) : nullptr;
   const int n_slice_tiles = (r_end + 63) >> 6;
   constexpr int D = 8;
+  int2 nb = make_int2(-1, 0x7fffffff);             // bounds of the next 64 tiles, requested one round ahead
+  if (use_tmin && lane < n_slice_tiles) nb = tmrow[lane];
   for (int tb = 0; tb < n_slice_tiles; tb += 64) {
     int tm = 0x7fffffff, tk = 0x7fffffff;            // tile bounds: smallest mismatch count, largest first key
-    if (tb + lane < n_slice_tiles) { if (use_tmin) { const int2 b_ = tmrow[tb + lane]; tm = b_.x; tk = b_.y; } else tm = -1; }
+    if (tb + lane < n_slice_tiles) { tm = nb.x; tk = nb.y; }
+    if (use_tmin && tb + 64 + lane < n_slice_tiles) nb = tmrow[tb + 64 + lane];
     // a tile can admit only if some reference passes the gate and (heap full) some reference's first key reaches the worst kept one
     // With consensus counters (CONS) a pre-score cut short at the snapshot lowers a pair's mismatch count, but never below the
     // snapshot, and never raises its first key: the bounds stay valid with "tm < T" widened to "tm < T or snapshot < T".
@@ -1751,8 +1781,11 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
     dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-    if (c->acgt) hipLaunchKernelGGL((scan3_kernel<16, true>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
-    else         hipLaunchKernelGGL((scan3_kernel<16, false>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first);
+#define SCAN3_LAUNCH(A, PFV) hipLaunchKernelGGL((scan3_kernel<16, A, PFV>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first)
+    const bool pf = c->scan_pf >= 0 ? c->scan_pf != 0 : nqt3 < 32;      // few query tiles per reference tile: planes come from HBM, not L2
+    if (c->acgt) { if (pf) SCAN3_LAUNCH(true, true); else SCAN3_LAUNCH(true, false); }
+    else         { if (pf) SCAN3_LAUNCH(false, true); else SCAN3_LAUNCH(false, false); }
+#undef SCAN3_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
@@ -1915,6 +1948,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
   if (c->scan_stream) hipStreamDestroy(c->scan_stream);
+  for (int i = 1; i < 3; i++) if (c->scan_streams[i]) hipStreamDestroy(c->scan_streams[i]);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1956,6 +1990,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     OPENCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     OPENCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
     OPENCHK(hipStreamCreateWithPriority(&c->scan_stream, hipStreamNonBlocking, prio_least));
+    c->scan_streams[0] = c->scan_stream;
+    for (int i = 1; i < 3; i++) OPENCHK(hipStreamCreateWithPriority(&c->scan_streams[i], hipStreamNonBlocking, prio_least));
     for (int i = 0; i < NBUF; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
   }
   uint8_t code_tab[256]; fill_code_table(code_tab);
@@ -2112,6 +2148,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       { const char *ep = getenv("UVAIA_GPU_REPLAY_LQ"); if (ep) c->replay_lq = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_SUBSLICE_MINQ"); if (ep) c->subslice_minq = atoi(ep); }
       c->serial = getenv("UVAIA_GPU_SERIAL") != nullptr;
+      { const char *ep = getenv("UVAIA_GPU_SCAN_PF"); if (ep) c->scan_pf = atoi(ep); }
       // Next to a running scan (8 blocks x 16.9 KB of LDS per CU) a replay block with the 22 KB query row fits once per CU, without
       // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
       if (c->replay_lq < 0) c->replay_lq = (c->nq < 256) ? 1 : 0;
@@ -2125,6 +2162,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       for (int t = 0; t < c->nq_pad / 16; t++) {
         sdir[(size_t)t * 2] = (uint32_t)strm.size();
         uint32_t nrec = 0;
+        size_t prev_hdr = (size_t)-1;
         for (int g = 0; g < c->W4; g++) {
           const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
           if ((fx | fy) == 0u) continue;
@@ -2142,9 +2180,12 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           uint32_t nw[4] = {0, 0, 0, 0};                // word items per word of the group, listed word by word
           auto word_of = [&](int q) { const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8; int j = 0; while (!(src[j] | src[4 + j])) j++; return j; };
           for (uint32_t m = f1; m; m &= m - 1) nw[word_of(__builtin_ctz(m))]++;
-          strm.push_back((uint32_t)g * 2048u | ((fx & 0xFFFFu) ? 1u : 0u) | ((fx >> 16) ? 2u : 0u));
+          const uint32_t hw0 = (uint32_t)g * 2048u | ((fx & 0xFFFFu) ? 1u : 0u) | ((fx >> 16) ? 2u : 0u) | (fy ? 4u : 0u);
+          if (prev_hdr != (size_t)-1) strm[prev_hdr + 3] = hw0;
+          prev_hdr = strm.size();
+          strm.push_back(hw0);
           strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u | nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19);
-          strm.push_back((uint32_t)__builtin_popcount(f4)); strm.push_back((uint32_t)g * 256u);
+          strm.push_back((uint32_t)__builtin_popcount(f4)); strm.push_back(0u);
           for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * 256u);
           while (strm.size() & 3) strm.push_back(16u * 256u);                                  // scratch row
           for (uint32_t m = f4; m; m &= m - 1) {
@@ -2213,7 +2254,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_ROW * sizeof(int)));
   OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_ROW * sizeof(int)));
-  if (!c->fullscan) OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
+  if (!c->fullscan) { OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2))); c->slice_cap[0] = (size_t)c->nq_pad * c->pool_pad; }
   OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   { const char *env_sub = getenv("UVAIA_GPU_SUBSLICE"); if (env_sub && atol(env_sub) >= 64) c->subslice = (size_t)atol(env_sub); }
   if (c->acgt && !c->fullscan && c->scan_variant == 2) OPENCHK(hipMalloc(&c->d_mp[0], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
@@ -2252,7 +2293,7 @@ int uvaia_gpu_reset(uvaia_gpu_ctx *c)
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->d_snap, &c->nchar, sizeof(int), hipMemcpyHostToDevice, c->stream));   // cq->max_incompatible = n_sites (src/nearest.c:375)
   if (c->d_entered && c->db_n) HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
-  if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
+  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -2372,7 +2413,7 @@ int uvaia_gpu_db_clear(uvaia_gpu_ctx *c)
   if (!c) return UVAIA_GPU_EINVAL;
   if (!c->d_db || !c->db_n) { c->db_n = 0; return 0; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
+  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   const size_t tiles = (c->db_n + 63) / 64;       // lanes past the last reference of a tile must read as zero planes
   HIPCHK(c, hipMemsetAsync(c->d_db, 0, tiles * (size_t)c->W4 * c->P * 64 * sizeof(uint4), c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_db_nonn, 0, tiles * 64 * sizeof(int), c->stream));
@@ -2447,9 +2488,12 @@ static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first
   // with few queries the replay is negligible and small launches only cost: one slice per pool then.  The sub-slice length is
   // tuned for 63 query tiles (1 000 queries); with fewer active tiles (query shards) it grows so that a launch still fills the chip
   const int nq_act = c->act_q1 - c->act_q0, nqt = (c->act_q1 + 15) / 16 - c->act_q0 / 16;
+  // Pool boundaries act through the snapshot only, and the snapshot only through the consensus counters: without constant-and-
+  // complete query columns (n_idx_c == 0) they have no effect at all and the slices are laid over the whole range.
+  if (c->n_idx_c == 0) pool = std::max<size_t>(n, 1);
   size_t sub = c->subslice;
   if (nqt < 63) sub = std::min(pool, (sub * 63 / (size_t)std::max(nqt, 1) + 63) / 64 * 64);
-  if (nq_act < c->subslice_minq) sub = pool;
+  if (nq_act < c->subslice_minq && (c->n_idx_c > 0 || nqt < 4)) sub = pool;
   for (size_t a = first; a < first + n; a += pool) {
     const size_t pe = std::min(first + n, a + pool);
     // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
@@ -2467,13 +2511,20 @@ static int run_subslices(uvaia_gpu_ctx *c, const std::vector<SubSlice> &subs, in
 {
   const size_t ns = subs.size();
   size_t issued = 0;
+  {   // a launch of fewer waves than ~2 rounds of the chip's 8 192 wave slots leaves it half empty at start and end: let such
+      // launches of consecutive slices overlap (they write different buffers)
+    const int nqt = (c->act_q1 + 15) / 16 - c->act_q0 / 16;
+    const size_t waves = ns ? (size_t)nqt * ((subs[0].n + 63) / 64) : 0;
+    const char *es = getenv("UVAIA_GPU_SCAN_STREAMS");
+    c->scan_nstreams = es ? std::min(3, std::max(1, atoi(es))) : (waves && waves < 30000 ? 3 : 1);
+  }
   for (size_t i = 0; i < ns; i++) {
     const bool serial_ = c->serial;
     while (issued < ns && issued < i + (serial_ ? 1 : NBUF)) {          // keep the scan stream fed
       int rc = uvaia_gpu_slice_scan(c, subs[issued].first, subs[issued].n, (int)(issued % NBUF));
       if (rc) return rc;
       issued++;
-      if (serial_) hipStreamSynchronize(c->scan_stream);
+      if (serial_) for (int i_ = 0; i_ < 3; i_++) hipStreamSynchronize(c->scan_streams[i_]);
     }
     int take = subs[i].pool_start ? 1 : 0;
     if (take && snapshot >= 0) { HIPCHK(c, hipMemcpyAsync(c->d_snap, &snapshot, sizeof(int), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); take = 0; }
@@ -2521,7 +2572,7 @@ int uvaia_gpu_search_resident_pool(uvaia_gpu_ctx *c, size_t first, size_t n, int
 int uvaia_gpu_sync(uvaia_gpu_ctx *c)
 {
   if (!c) return UVAIA_GPU_EINVAL;
-  if (c->scan_stream) HIPCHK(c, hipStreamSynchronize(c->scan_stream));
+  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return collect_events(c);
 }
@@ -2622,20 +2673,37 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
 {
   if (!c || buf < 0 || buf >= NBUF) return UVAIA_GPU_EINVAL;
   if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "ring mode needs the two-counter scan");
-  if (first + n > c->db_n || n > c->max_pool) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database or above max_pool", first, n);
-  if (buf > 0 && !c->d_cntb[buf]) HIPCHK(c, hipMalloc(&c->d_cntb[buf], (size_t)c->nq_pad * c->pool_pad * sizeof(int2)));
-  if (!c->d_tmin[buf]) HIPCHK(c, hipMalloc(&c->d_tmin[buf], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
-  if (c->d_mp[0] && !c->d_mp[buf]) HIPCHK(c, hipMalloc(&c->d_mp[buf], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
-  if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(c->scan_stream, c->replay_done[buf], 0));   // the buffer's previous reader
+  if (first + n > c->db_n) return fail(c, UVAIA_GPU_EINVAL, "slice [%zu,+%zu) outside the database", first, n);
+  // a slice is at most a pool when the batch snapshot can matter (n_idx_c > 0); otherwise pools have no effect and slices are free
+  if (n > c->max_pool && c->n_idx_c > 0) return fail(c, UVAIA_GPU_EINVAL, "slice of %zu references above max_pool %zu", n, c->max_pool);
+  {
+    const size_t ppad_ = ((first + n + 63) / 64 - first / 64) * 64;
+    const size_t rows = std::min<size_t>((size_t)c->nq_pad, ((size_t)c->act_q1 + 15) / 16 * 16);     // the scan writes whole query tiles up to the last active one
+    const size_t need = std::max(rows * ppad_, buf == 0 ? c->slice_cap[0] : (size_t)0);
+    if (need > c->slice_cap[buf] || !c->d_tmin[buf]) {
+      for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const size_t cap = std::max(need, (size_t)c->nq_pad * c->pool_pad);
+      int2 *&cb = buf ? c->d_cntb[buf] : c->d_cnt2;
+      if (cap > c->slice_cap[buf] || !cb) { if (cb) hipFree(cb); cb = nullptr; HIPCHK(c, hipMalloc(&cb, cap * sizeof(int2))); }
+      if (c->d_tmin[buf]) hipFree(c->d_tmin[buf]);
+      c->d_tmin[buf] = nullptr;
+      HIPCHK(c, hipMalloc(&c->d_tmin[buf], (cap / 64) * sizeof(int2)));
+      if (c->d_mp[0] || (c->acgt && c->scan_variant == 2)) { if (c->d_mp[buf]) hipFree(c->d_mp[buf]); c->d_mp[buf] = nullptr; HIPCHK(c, hipMalloc(&c->d_mp[buf], cap * sizeof(int))); }
+      c->slice_cap[buf] = cap;
+    }
+  }
+  hipStream_t ss = c->scan_streams[c->scan_nstreams > 1 ? (c->scan_rr++ % c->scan_nstreams) : 0];
+  if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(ss, c->replay_done[buf], 0));   // the buffer's previous reader
   const long long tf = (long long)(first / 64);
   const int n_tiles = n ? (int)((first + n + 63) / 64 - first / 64) : 0;
   c->slice_tf[buf] = tf; c->slice_tiles[buf] = n_tiles;
   c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
   c->slice_scanned[buf] = true; c->slice_cons_done[buf] = false;
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, c->scan_stream, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_mp[buf]);
+  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, ss, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_mp[buf]);
   if (rc) return rc;
-  HIPCHK(c, hipEventRecord(c->scan_done[buf], c->scan_stream));
+  HIPCHK(c, hipEventRecord(c->scan_done[buf], ss));
   return 0;
 }
 

@@ -51,6 +51,7 @@ namespace {
 constexpr int HEAP_ENTRY = 8;          // 6 scores + 64-bit ordinal (lo, hi)
 constexpr int AMB_CAP = 11;            // alignment words with a partially ambiguous site remembered per sequence
 constexpr int AMB_STRIDE = AMB_CAP + 1;  // ints per QUERY: count (uncapped) + word indices
+constexpr int SCAN_LOCKSTEP = 2;       // scan3, qblock mode: word groups between two barriers of a block
 constexpr int AMB_ROW = 64;            // ints per REFERENCE side row (256 B, one coalesced wave load):
                                        //   [0] count (uncapped)  [1..11] word indices  [12 + 4k + p] plane p of the k-th listed word
 constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
@@ -99,6 +100,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
+  int scan_qblock = -1;          // UVAIA_GPU_SCAN_QBLOCK: block = 4 query tiles x 1 reference tile (1) or 1 x 4 (0); default by active query tiles
   int scan_pf = -1;              // UVAIA_GPU_SCAN_PF: force the plane prefetch of the scan on (1) / off (0); default by active query tiles
   bool serial = false;           // UVAIA_GPU_SERIAL: no scan/replay overlap (to time the kernels in isolation)
   int subslice_minq = 256;       // sub-slicing of pools only from this many active queries (UVAIA_GPU_SUBSLICE_MINQ)
@@ -686,17 +688,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                      const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
                                                      const int *__restrict__ tot_e, const int *__restrict__ tot_v,
                                                      int2 *__restrict__ out, int ppad, int n_qtiles, int2 *__restrict__ tmin, int r_lo, int r_hi,
-                                                     int *__restrict__ mp_out, int parts, int qtile_first)
+                                                     int *__restrict__ mp_out, int parts, int qtile_first, int qblock)
 {
   static_assert(QT == 16, "stream offsets are laid out for tiles of 16 queries");
   constexpr uint32_t RARE_BIAS = 8192u;                      // the low counter half also takes what rare items give back: keep it positive
   __shared__ uint32_t lacc[4][QT + 1][64];                     // per wave: one packed counter per (query, lane) + a scratch row
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int qtile, group;
-  if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: say so
+  int qtile, group, trel;
+  if (qblock) {   // the four waves of a block = four query tiles over ONE reference tile: with few query tiles the passes over a tile
+    int qg;       // then share its planes in L1/L2 instead of drifting apart and re-reading them from HBM
+    if (!scan_work_item((n_qtiles + 3) / 4, n_tiles, qg, group)) return;
+    qtile = qg * 4 + wave; trel = group;
+    if (qtile >= n_qtiles) {          // no query tile for this wave: it only keeps the block's barriers company
+      for (int cp = 0; cp < W4; cp += SCAN_LOCKSTEP) __builtin_amdgcn_s_barrier();
+      return;
+    }
+  } else {        // four reference tiles, one query tile
+    if (!scan_work_item(n_qtiles, (n_tiles + 3) / 4, qtile, group)) return;
+    trel = group * 4 + wave;
+    if (trel >= n_tiles) return;
+  }
   qtile += qtile_first;                                        // only the active query tiles are scanned (query shards)
-  const int trel = group * 4 + wave;
-  if (trel >= n_tiles) return;
   const int q0 = qtile * QT;
   const size_t r = (size_t)trel * 64 + lane;
   typedef __attribute__((address_space(3))) uint32_t lds_u32;   // explicit LDS pointer: the stream loads stay scalar (no may-alias with the atomics)
@@ -773,11 +785,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (hf & 2u) nV = *reinterpret_cast<const uint4 *>(tg + 1024);
       if (hf & 4u) ng = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + ((hf & ~1023u) >> 3));
     }
+    // qblock: the four waves of the block walk the SAME reference tile for four query tiles.  They are kept within SCAN_LOCKSTEP
+    // word groups of each other by barriers, so that a plane fetched by one of them is still in L1/L2 when the others want it
+    // (left alone they drift apart and every pass re-reads the tile from HBM: 4x the traffic at 8 query tiles, FETCH_SIZE).
+    int next_cp = 0;
     for (uint32_t rec = 0; rec < (dir.y & 0xFFFFu); rec++) {
       QWords<4> h;
       load_qwords(h, sp);
       const uint32_t h0 = h.v[0], n_full4 = h.v[1] & 15u, n_words = h.v[1] >> 4, n_gen = h.v[2];
       sp += 4;
+      if (qblock) for (const int g_ = (int)(h0 >> 11); next_cp <= g_; next_cp += SCAN_LOCKSTEP) __builtin_amdgcn_s_barrier();
       if (PF) {
         pE = nE; pV = nV; g = ng;
         const uint32_t hn = h.v[3];                                                    // first header word of the next record (0 after the last)
@@ -836,6 +853,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #undef WORD_ITEMS
       }
     }
+    if (qblock) for (; next_cp < W4; next_cp += SCAN_LOCKSTEP) __builtin_amdgcn_s_barrier();   // every wave passes the same number of barriers
     // ---- rare columns: the queries that do not carry a rare column's majority base were made dirty there above (their E bit is
     // taken away); here they get the true comparison on the gathered planes of the rare columns, as a negative deficit
     {
@@ -1780,8 +1798,9 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
-    dim3 grid3(scan_grid_size(nqt3, (n_tiles + 3) / 4));
-#define SCAN3_LAUNCH(A, PFV) hipLaunchKernelGGL((scan3_kernel<16, A, PFV>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first)
+    const int qblock = c->scan_qblock >= 0 ? c->scan_qblock : (nqt3 == 3 || nqt3 == 4 ? 1 : 0);      // measured: helps with one block of query tiles per reference tile (33..64 queries), not beyond
+    dim3 grid3(qblock ? scan_grid_size((nqt3 + 3) / 4, n_tiles) : scan_grid_size(nqt3, (n_tiles + 3) / 4));
+#define SCAN3_LAUNCH(A, PFV) hipLaunchKernelGGL((scan3_kernel<16, A, PFV>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first, qblock)
     const bool pf = c->scan_pf >= 0 ? c->scan_pf != 0 : nqt3 < 32;      // few query tiles per reference tile: planes come from HBM, not L2
     if (c->acgt) { if (pf) SCAN3_LAUNCH(true, true); else SCAN3_LAUNCH(true, false); }
     else         { if (pf) SCAN3_LAUNCH(false, true); else SCAN3_LAUNCH(false, false); }
@@ -2149,6 +2168,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       { const char *ep = getenv("UVAIA_GPU_SUBSLICE_MINQ"); if (ep) c->subslice_minq = atoi(ep); }
       c->serial = getenv("UVAIA_GPU_SERIAL") != nullptr;
       { const char *ep = getenv("UVAIA_GPU_SCAN_PF"); if (ep) c->scan_pf = atoi(ep); }
+      { const char *ep = getenv("UVAIA_GPU_SCAN_QBLOCK"); if (ep) c->scan_qblock = atoi(ep); }
       // Next to a running scan (8 blocks x 16.9 KB of LDS per CU) a replay block with the 22 KB query row fits once per CU, without
       // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
       if (c->replay_lq < 0) c->replay_lq = (c->nq < 256) ? 1 : 0;

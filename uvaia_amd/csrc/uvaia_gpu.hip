@@ -16,12 +16,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/uvaia_gpu.h"
@@ -1736,6 +1738,18 @@ namespace {
 
 // Packs one character row restricted to `keep` (nullable: keep everything inside [lo,hi)) into query-plane words:
 // dst[(w4*4 + j)*NQ + plane].  is_poly marks query->idx columns (--acgt: fourth plane).
+// host-side preparation of a query set is O(queries x columns) several times over: spread the independent pieces over threads
+template <class F>
+static void parallel_for(int n, F f)
+{
+  const unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (n < 32 || nt < 2) { for (int i = 0; i < n; i++) f(i); return; }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { for (;;) { const int a = next.fetch_add(4); if (a >= n) break; for (int i = a; i < std::min(n, a + 4); i++) f(i); } });
+  for (auto &x : th) x.join();
+}
+
 int pack_query_row(const uint8_t *code_tab, const char *row, int nchar, int lo, int hi, const uint8_t *keep, const uint8_t *is_poly,
                    bool acgt, int NQ, uint32_t *dst, int *bad_byte)
 {
@@ -2025,11 +2039,20 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   for (int i = 0; i < q->n_idx; i++)   if (q->idx[i]   < (size_t)c->nchar) in_p[q->idx[i]] = 1;
   std::vector<uint32_t> qp((size_t)c->nq_pad * row_words, 0u), cp(row_words, 0u), cpm(row_words, 0u), qpoly((size_t)c->nq_pad * row_words, 0u);
   int bad = 0;
-  for (int i = 0; i < c->nq; i++) {
-    if (!q->seq[i]) { uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", i); }
-    if (pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, nullptr, in_p.data(), c->acgt, c->NQ, qp.data() + (size_t)i * row_words, &bad) ||
-        pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, in_p.data(), in_p.data(), c->acgt, c->NQ, qpoly.data() + (size_t)i * row_words, &bad)) {
-      uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EALPHABET, "query %d holds byte 0x%02x outside the supported alphabet", i, bad);
+  for (int i = 0; i < c->nq; i++) if (!q->seq[i]) { uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", i); }
+  {
+    std::atomic<int> first_bad(c->nq);
+    std::vector<int> bad_byte((size_t)c->nq, 0);
+    parallel_for(c->nq, [&](int i) {
+      if (pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, nullptr, in_p.data(), c->acgt, c->NQ, qp.data() + (size_t)i * row_words, &bad_byte[(size_t)i]) ||
+          pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, in_p.data(), in_p.data(), c->acgt, c->NQ, qpoly.data() + (size_t)i * row_words, &bad_byte[(size_t)i])) {
+        int cur = first_bad.load();
+        while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+      }
+    });
+    if (first_bad.load() < c->nq) {
+      const int i = first_bad.load();
+      uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EALPHABET, "query %d holds byte 0x%02x outside the supported alphabet", i, bad_byte[(size_t)i]);
     }
   }
   if (pack_query_row(code_tab, q->consensus, c->nchar, 0, c->nchar, in_c.data(), nullptr, c->acgt, c->NQ, cp.data(), &bad) ||
@@ -2042,27 +2065,27 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     if (!c->acgt) {
       const size_t row2 = (size_t)c->W4 * 16;
       std::vector<uint32_t> qp2((size_t)c->nq_pad * row2, 0u);
-      for (int i = 0; i < c->nq; i++) for (int w = 0; w < c->W4 * 4; w++) {
+      parallel_for(c->nq, [&](int i) { for (int w = 0; w < c->W4 * 4; w++) {
         const uint32_t *s6 = qp.data() + (size_t)i * row_words + (size_t)w * 6;
         uint32_t *d4 = qp2.data() + (size_t)i * row2 + (size_t)w * 4;
         const uint32_t one = s6[5];
         d4[0] = (s6[1] | s6[3]) & one; d4[1] = (s6[2] | s6[3]) & one; d4[2] = one; d4[3] = s6[4];
         if (s6[4] & ~one) { int &cnt = ambq[(size_t)i * AMB_STRIDE]; if (cnt < AMB_CAP) ambq[(size_t)i * AMB_STRIDE + 1 + cnt] = w; cnt++; }
-      }
+      } });
       OPENCHK(hipMalloc(&c->d_qp2, qp2.size() * 4)); OPENCHK(hipMemcpy(c->d_qp2, qp2.data(), qp2.size() * 4, hipMemcpyHostToDevice));
     }
     {  // LDS-staging layout: [query tile of 16][w4 (padded to 8)][query in tile][word j] -> uint4 of the four planes
       c->W4pad = (c->W4 + 7) / 8 * 8;
       const int ntile = c->nq_pad / 16;
       std::vector<uint32_t> qvh((size_t)ntile * c->W4pad * 16 * 4 * 4, 0u);
-      for (int i = 0; i < c->nq; i++) for (int w = 0; w < c->W4 * 4; w++) {
+      parallel_for(c->nq, [&](int i) { for (int w = 0; w < c->W4 * 4; w++) {
         uint32_t pl[4];
         if (c->acgt) { const uint32_t *s4 = qp.data() + (size_t)i * row_words + (size_t)w * 4; pl[0] = s4[0]; pl[1] = s4[1]; pl[2] = s4[2]; pl[3] = s4[3]; }
         else { const uint32_t *s6 = qp.data() + (size_t)i * row_words + (size_t)w * 6; const uint32_t one = s6[5];
                pl[0] = (s6[1] | s6[3]) & one; pl[1] = (s6[2] | s6[3]) & one; pl[2] = one; pl[3] = s6[4]; }
         uint32_t *d = qvh.data() + ((((size_t)(i / 16) * c->W4pad + (w >> 2)) * 16 + (i % 16)) * 4 + (w & 3)) * 4;
         d[0] = pl[0]; d[1] = pl[1]; d[2] = pl[2]; d[3] = pl[3];
-      }
+      } });
       OPENCHK(hipMalloc(&c->d_qv, qvh.size() * 4)); OPENCHK(hipMemcpy(c->d_qv, qvh.data(), qvh.size() * 4, hipMemcpyHostToDevice));
     }
     {  // column classes and compressed/dirty query planes for scan3_kernel
@@ -2073,7 +2096,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         return pl == 0 ? ((s6[1] | s6[3]) & one) : pl == 1 ? ((s6[2] | s6[3]) & one) : pl == 2 ? one : s6[4];
       };
       std::vector<uint32_t> cls((size_t)Wp * 4, 0u);
-      for (int w = 0; w < Wp; w++) {
+      parallel_for(Wp, [&](int w) {
         uint32_t cL = 0, cH = 0, seen = 0, poly = 0;
         for (int i = 0; i < c->nq; i++) {
           const uint32_t qL = QL(i, w, 0), qH = QL(i, w, 1), qI = QL(i, w, 2);
@@ -2082,7 +2105,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           cL |= qL & fresh; cH |= qH & fresh; seen |= qI;
         }
         cls[(size_t)w * 4 + 0] = cL & ~poly; cls[(size_t)w * 4 + 1] = cH & ~poly; cls[(size_t)w * 4 + 2] = seen & ~poly; cls[(size_t)w * 4 + 3] = poly;
-      }
+      });
       // Rare columns: polymorphic, but all except a few queries carry the same base (private mutations, sequencing noise: 95 % of
       // the polymorphic columns of the benchmark queries).  They are handled like constant columns with that base; the few
       // queries that differ are "dirty" there (their E bit is taken away by the usual items) and get the true comparison from a
@@ -2094,11 +2117,10 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         if (c->fullscan || c->scan_variant != 2) c->rare_max = 0;
       }
       if (c->rare_max > 0) {
-        std::vector<int> cnt(32 * 4);
-        for (int w = 0; w < Wp; w++) {
+        parallel_for(Wp, [&](int w) {
           const uint32_t pm = cls[(size_t)w * 4 + 3];
-          if (!pm) continue;
-          std::fill(cnt.begin(), cnt.end(), 0);
+          if (!pm) return;
+          int cnt[32 * 4] = {0};
           for (int i = 0; i < c->nq; i++) {
             const uint32_t qL = QL(i, w, 0), qH = QL(i, w, 1);
             for (uint32_t m = QL(i, w, 2) & pm; m; m &= m - 1) { const int b = __builtin_ctz(m); cnt[(size_t)b * 4 + (((qL >> b) & 1u) | (((qH >> b) & 1u) << 1))]++; }
@@ -2113,7 +2135,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
             cls[(size_t)w * 4 + 1] = (cls[(size_t)w * 4 + 1] & ~bit) | ((major & 2) ? bit : 0u);
             cls[(size_t)w * 4 + 2] |= bit; cls[(size_t)w * 4 + 3] &= ~bit; rmask[(size_t)w] |= bit;
           }
-        }
+        });
       }
       for (int w = 0; w < Wp; w++) { c->NP += __builtin_popcount(cls[(size_t)w * 4 + 3]); c->NR += __builtin_popcount(rmask[(size_t)w]); }
       c->NP4 = ((c->NP + 31) / 32 + 3) / 4;
@@ -2123,7 +2145,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       std::vector<uint32_t> qrare((size_t)c->nq * std::max(c->NR4, 1) * 12, 0u);
       const size_t prow = (size_t)std::max(c->NP4, 1) * 16, crow = (size_t)c->W4 * 8;
       std::vector<uint32_t> qpl((size_t)c->nq_pad * prow, 0u), qcv((size_t)c->nq_pad * crow, 0u), flg((size_t)(c->nq_pad / 16) * c->W4 * 2, 0u);
-      for (int i = 0; i < c->nq_pad; i++) {
+      parallel_for(c->nq_pad / 16, [&](int tile_) { for (int i = tile_ * 16; i < tile_ * 16 + 16; i++) {   // a tile's 16 queries share flag words
         int k = 0, kr = 0;                                           // compressed bit position among the dense / the rare columns
         bool full = false;                                           // all 128 columns of the current word group are N/gap
         for (int w = 0; w < Wp; w++) {
@@ -2154,7 +2176,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           full = full && nI == cls[(size_t)w * 4 + 2] && nV == 0xFFFFFFFFu;
           if ((w & 3) == 3 && full) { fw[0] &= ~(0x10001u << (i % 16)); fw[1] |= 1u << (i % 16); }
         }
-      }
+      } });
       for (int g = 0; g < c->W4; g++) {
         uint32_t u = 0;
         uint32_t uy = 0;

@@ -129,21 +129,35 @@ create_query_indices (query_t qu)
   qu->idx_m = (size_t *) biomcmc_realloc (qu->idx_m, (span + 1) * sizeof (size_t));
   qu->idx   = (size_t *) biomcmc_realloc (qu->idx,   (span + 1) * sizeof (size_t));
   qu->n_idx_c = qu->n_idx_m = qu->n_idx = 0;
-  for (int col = lo; col < hi; col++) {
-    char shared = 'N';
-    int missing = 0, j;
-    for (j = 0; j < n; j++) {
-      char c = s[j][col];
-      if (!usable (qu, c)) { missing = 1; continue; }
-      if (shared == 'N') shared = c;
-      else if (shared != c) break;           /* polymorphic: later sequences cannot change that */
-    }
-    if (j < n) { qu->consensus[col] = '#'; qu->idx[qu->n_idx++] = (size_t) col; }
-    else if (shared != 'N') {
-      qu->consensus[col] = shared;
-      if (missing) qu->idx_m[qu->n_idx_m++] = (size_t) col; else qu->idx_c[qu->n_idx_c++] = (size_t) col;
+  /* Per column: the first usable character, whether a later usable one differs (polymorphic) and whether some query is not
+     usable there.  Walked query by query (rows are contiguous) in blocks of columns, one block per thread: same classes as a
+     column-by-column walk over the queries, without its strided reads. */
+  char *shared = (char *) biomcmc_malloc ((size_t) (L > 0 ? L : 1));
+  unsigned char *flags = (unsigned char *) biomcmc_malloc ((size_t) (L > 0 ? L : 1));      /* bit 0: polymorphic, bit 1: some query missing */
+  memset (shared, 'N', (size_t) (L > 0 ? L : 1));
+  memset (flags, 0, (size_t) (L > 0 ? L : 1));
+  const int block = 2048;
+#pragma omp parallel for schedule(dynamic)
+  for (int b0 = lo; b0 < hi; b0 += block) {
+    const int b1 = b0 + block < hi ? b0 + block : hi;
+    for (int j = 0; j < n; j++) {
+      const char *row = s[j];
+      for (int col = b0; col < b1; col++) {
+        const char c = row[col];
+        if (!usable (qu, c)) flags[col] |= 2;
+        else if (shared[col] == 'N') shared[col] = c;
+        else if (shared[col] != c) flags[col] |= 1;
+      }
     }
   }
+  for (int col = lo; col < hi; col++) {
+    if (flags[col] & 1) { qu->consensus[col] = '#'; qu->idx[qu->n_idx++] = (size_t) col; }
+    else if (shared[col] != 'N') {
+      qu->consensus[col] = shared[col];
+      if (flags[col] & 2) qu->idx_m[qu->n_idx_m++] = (size_t) col; else qu->idx_c[qu->n_idx_c++] = (size_t) col;
+    }
+  }
+  free (shared); free (flags);
   fprintf (stderr, "Query sequence alignment: %d segregating, %d non-segregating sites with indels, and %d constant sites (all are used in comparisons)\n",
            qu->n_idx, qu->n_idx_m, qu->n_idx_c);
 }
@@ -163,6 +177,7 @@ reorder_query_structure (query_t qu)
   const size_t span = (size_t) qu->aln->nchar - 2 * qu->trim;
   keyed_pos *kp = (keyed_pos *) biomcmc_malloc ((size_t) (n > 0 ? n : 1) * sizeof *kp);
   int *order = (int *) biomcmc_malloc ((size_t) (n > 0 ? n : 1) * sizeof (int));
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; i++) {
     char *s = qu->aln->character->string[i] + qu->trim;
     kp[i].pos = i;

@@ -38,13 +38,20 @@ uvaia_keep_only_valid_sequences (alignment aln, double ambiguity, bool check_ali
 {
   int *kept = (int *) biomcmc_malloc ((size_t) (aln->ntax > 0 ? aln->ntax : 1) * sizeof (int)), n_kept = 0;
   long common_length = 0;   /* 0 = none seen yet, -1 = lengths differ */
-  double f[3];
-  for (int i = 0; i < aln->character->nstrings; i++) {
+  /* the per-sequence work (upper-casing, character census) is independent: all host threads; the decisions stay in file order */
+  const int ns = aln->character->nstrings;
+  double *fr = (double *) biomcmc_malloc ((size_t) (ns > 0 ? ns : 1) * 3 * sizeof (double));
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < ns; i++) {
     size_t len = aln->character->nchars[i];
-    char *s = aln->character->string[i];
+    if (len < 5) continue;
+    upper_kseq (aln->character->string[i], (unsigned) len);
+    biomcmc_count_sequence_acgt (aln->character->string[i], len, fr + (size_t) i * 3);
+  }
+  for (int i = 0; i < ns; i++) {
+    size_t len = aln->character->nchars[i];
+    const double *f = fr + (size_t) i * 3;
     if (len < 5) { fprintf (stderr, "Sequence %s is too short ( = %zu sites), limit is hardcoded at 5bps.\n", aln->taxlabel->string[i], len); continue; }
-    upper_kseq (s, (unsigned) len);
-    biomcmc_count_sequence_acgt (s, len, f);
     if (f[2] > ambiguity) { fprintf (stderr, "Sequence %s has proportion of N etc. (=%lf) above threshold of %lf\n", aln->taxlabel->string[i], f[2], ambiguity); continue; }
     if (f[0] < 1. - 1.1 * ambiguity) { fprintf (stderr, "Sequence %s has proportion of ACGT (=%lf) below threshold of %lf\n", aln->taxlabel->string[i], f[0], 1. - 1.1 * ambiguity); continue; }
     kept[n_kept++] = i;
@@ -58,5 +65,5 @@ uvaia_keep_only_valid_sequences (alignment aln, double ambiguity, bool check_ali
   char_vector_reduce_to_valid_strings (aln->character, kept, n_kept);
   char_vector_reduce_to_valid_strings (aln->taxlabel, kept, n_kept);
   aln->ntax = n_kept;
-  free (kept);
+  free (kept); free (fr);
 }

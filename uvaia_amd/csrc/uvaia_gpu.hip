@@ -103,7 +103,6 @@ struct uvaia_gpu_ctx {
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
   int scan_qblock = -1;          // UVAIA_GPU_SCAN_QBLOCK: block = 4 query tiles x 1 reference tile (1) or 1 x 4 (0); default by active query tiles
-  int scan_pf = -1;              // UVAIA_GPU_SCAN_PF: force the plane prefetch of the scan on (1) / off (0); default by active query tiles
   bool serial = false;           // UVAIA_GPU_SERIAL: no scan/replay overlap (to time the kernels in isolation)
   int subslice_minq = 256;       // sub-slicing of pools only from this many active queries (UVAIA_GPU_SUBSLICE_MINQ)
   int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
@@ -676,7 +675,7 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 //   out.x = ACGT matches (default) or ACGT mismatches (--acgt),  out.y = valid pairs (default) or comparable sites (--acgt)
 // stream (dwords), per query tile, sdir[qtile] = {first dword, number of group records | number of rare records << 16}:
 //   record = { w4 * 2048 (byte offset of the group's E plane in the tile) | needE | needV << 1,  n_full4 = ceil(n_full / 4),  n_generic,
-//              first word of the NEXT record (0 after the last) }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
+//              length of the record in dwords }  + 4 n_full4 LDS offsets (padded with the scratch row 16 * 256)
 //            (bit 2 of the first word: some query is all-N here, the group's grp[] row at byte offset w4 * 256 is needed)
 //            + n_generic x { ~qI & constMask [4],  ~qV (default) / ~qI (--acgt) [4],  LDS offset, 0, 0, 0 }
 //            + word items { ~qI & constMask, ~qV, LDS offset, 0 } of the queries that are dirty in ONE word of the group only, listed word
@@ -684,7 +683,7 @@ __global__ __launch_bounds__(64) void gather_poly_kernel(const uint4 *__restrict
 //   rare record (after the group records) = { byte offset of a rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }
 //            + items { sites, their lo bits, their hi bits, LDS offset }, word by word
 // qpl[q][p4][L,H,I,-][4]: compressed planes of the polymorphic columns
-template <int QT, bool ACGT, bool PF>
+template <int QT, bool ACGT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void scan3_kernel(const uint4 *__restrict__ ev, const uint4 *__restrict__ poly, long long tile_first, int n_tiles,
                                                      int W4, int NP4, int NPT, const uint32_t *__restrict__ qpl, const uint32_t *__restrict__ stream,
                                                      const uint2 *__restrict__ sdir, const uint32_t *__restrict__ grp,
@@ -771,41 +770,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       LDS_ADD(it.v[8], (uint32_t)e_ | ((uint32_t)v_ << 16));                                                        \
     }
 #define TOUCH_ITEM(it) asm volatile("" ::"s"(it.v[0]), "s"(it.v[1]), "s"(it.v[2]), "s"(it.v[3]), "s"(it.v[4]), "s"(it.v[5]), "s"(it.v[6]), "s"(it.v[7]), "s"(it.v[8]))
-    // PF (few active query tiles: a reference's planes are no longer found in L2 by the later tiles, every record then waits a
-    // full HBM round trip): the planes of the NEXT record are requested before the current one is counted; its first header
-    // word travels in the current header.  A plane that no item of a record needs is not loaded; its registers then hold
-    // whatever they held, which is harmless: every use is an AND with a mask word that is zero for such a plane.  (The empty asm
-    // only tells the compiler the registers are defined, so that it does not spend moves on zeroing them.)
-    uint4 pE, pV, nE, nV;
-    uint32_t g = 0u, ng = 0u;
+    // A plane that no item of a record needs is not loaded; its registers then hold whatever they held, which is harmless: every
+    // use is an AND with a mask word that is zero for such a plane.  (The empty asm only tells the compiler the registers are
+    // defined, so that it does not spend moves on zeroing them.)  The header of the NEXT record is requested as soon as the
+    // current one is known (its length travels in the header): the walk never waits for a header.
+    uint4 pE, pV;
+    uint32_t g = 0u;
     asm volatile("" : "=v"(pE.x), "=v"(pE.y), "=v"(pE.z), "=v"(pE.w), "=v"(pV.x), "=v"(pV.y), "=v"(pV.z), "=v"(pV.w));
-    asm volatile("" : "=v"(nE.x), "=v"(nE.y), "=v"(nE.z), "=v"(nE.w), "=v"(nV.x), "=v"(nV.y), "=v"(nV.z), "=v"(nV.w));
-    if (PF && (dir.y & 0xFFFFu)) {
-      const uint32_t hf = sp[0];
-      const char *tg = reinterpret_cast<const char *>(t) + (hf & ~1023u);
-      if (hf & 1u) nE = *reinterpret_cast<const uint4 *>(tg);
-      if (hf & 2u) nV = *reinterpret_cast<const uint4 *>(tg + 1024);
-      if (hf & 4u) ng = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + ((hf & ~1023u) >> 3));
-    }
     // qblock: the four waves of the block walk the SAME reference tile for four query tiles.  They are kept within SCAN_LOCKSTEP
     // word groups of each other by barriers, so that a plane fetched by one of them is still in L1/L2 when the others want it
     // (left alone they drift apart and every pass re-reads the tile from HBM: 4x the traffic at 8 query tiles, FETCH_SIZE).
     int next_cp = 0;
+    QWords<4> h;
+    load_qwords(h, sp);
     for (uint32_t rec = 0; rec < (dir.y & 0xFFFFu); rec++) {
-      QWords<4> h;
-      load_qwords(h, sp);
       const uint32_t h0 = h.v[0], n_full4 = h.v[1] & 15u, n_words = h.v[1] >> 4, n_gen = h.v[2];
+      const cst_u32 *sp_next = sp + h.v[3];
+      QWords<4> hn;
+      load_qwords(hn, sp_next);                 // past the last record this reads the next tile's first header or the padding
       sp += 4;
       if (qblock) for (const int g_ = (int)(h0 >> 11); next_cp <= g_; next_cp += SCAN_LOCKSTEP) __builtin_amdgcn_s_barrier();
-      if (PF) {
-        pE = nE; pV = nV; g = ng;
-        const uint32_t hn = h.v[3];                                                    // first header word of the next record (0 after the last)
-        const char *tn = reinterpret_cast<const char *>(t) + (hn & ~1023u);
-        if (hn & 1u) nE = *reinterpret_cast<const uint4 *>(tn);
-        if (hn & 2u) nV = *reinterpret_cast<const uint4 *>(tn + 1024);
-        if (hn & 4u) ng = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gt) + ((hn & ~1023u) >> 3));
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
+      {
         const char *tg = reinterpret_cast<const char *>(t) + (h0 & ~1023u);            // E plane of the group, V plane 1 KiB further
         if (h0 & 1u) pE = *reinterpret_cast<const uint4 *>(tg);
         if (h0 & 2u) pV = *reinterpret_cast<const uint4 *>(tg + 1024);
@@ -854,6 +839,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         WORD_ITEMS(0) WORD_ITEMS(1) WORD_ITEMS(2) WORD_ITEMS(3)
 #undef WORD_ITEMS
       }
+      sp = sp_next; h = hn;
     }
     if (qblock) for (; next_cp < W4; next_cp += SCAN_LOCKSTEP) __builtin_amdgcn_s_barrier();   // every wave passes the same number of barriers
     // ---- rare columns: the queries that do not carry a rare column's majority base were made dirty there above (their E bit is
@@ -1814,10 +1800,8 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
     const int qblock = c->scan_qblock >= 0 ? c->scan_qblock : (nqt3 == 3 || nqt3 == 4 ? 1 : 0);      // measured: helps with one block of query tiles per reference tile (33..64 queries), not beyond
     dim3 grid3(qblock ? scan_grid_size((nqt3 + 3) / 4, n_tiles) : scan_grid_size(nqt3, (n_tiles + 3) / 4));
-#define SCAN3_LAUNCH(A, PFV) hipLaunchKernelGGL((scan3_kernel<16, A, PFV>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first, qblock)
-    const bool pf = c->scan_pf >= 0 ? c->scan_pf != 0 : nqt3 < 32;      // few query tiles per reference tile: planes come from HBM, not L2
-    if (c->acgt) { if (pf) SCAN3_LAUNCH(true, true); else SCAN3_LAUNCH(true, false); }
-    else         { if (pf) SCAN3_LAUNCH(false, true); else SCAN3_LAUNCH(false, false); }
+#define SCAN3_LAUNCH(A) hipLaunchKernelGGL((scan3_kernel<16, A>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first, qblock)
+    if (c->acgt) SCAN3_LAUNCH(true); else SCAN3_LAUNCH(false);
 #undef SCAN3_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
@@ -2189,7 +2173,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       { const char *ep = getenv("UVAIA_GPU_REPLAY_LQ"); if (ep) c->replay_lq = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_SUBSLICE_MINQ"); if (ep) c->subslice_minq = atoi(ep); }
       c->serial = getenv("UVAIA_GPU_SERIAL") != nullptr;
-      { const char *ep = getenv("UVAIA_GPU_SCAN_PF"); if (ep) c->scan_pf = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_SCAN_QBLOCK"); if (ep) c->scan_qblock = atoi(ep); }
       // Next to a running scan (8 blocks x 16.9 KB of LDS per CU) a replay block with the 22 KB query row fits once per CU, without
       // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
@@ -2223,7 +2206,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           auto word_of = [&](int q) { const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8; int j = 0; while (!(src[j] | src[4 + j])) j++; return j; };
           for (uint32_t m = f1; m; m &= m - 1) nw[word_of(__builtin_ctz(m))]++;
           const uint32_t hw0 = (uint32_t)g * 2048u | ((fx & 0xFFFFu) ? 1u : 0u) | ((fx >> 16) ? 2u : 0u) | (fy ? 4u : 0u);
-          if (prev_hdr != (size_t)-1) strm[prev_hdr + 3] = hw0;
           prev_hdr = strm.size();
           strm.push_back(hw0);
           strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u | nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19);
@@ -2243,6 +2225,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
               const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
               strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)q * 256u); strm.push_back(0u);
             }
+          strm[prev_hdr + 3] = (uint32_t)(strm.size() - prev_hdr);
           nrec++;
         }
         // rare records: { byte offset of the rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }

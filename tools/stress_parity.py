@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle campaign (run on the GPU box): shapes, modes and engine switches drawn at random; every search must
+give the oracle's heaps, tolerances and dump flags, streamed and resident.  python tools/stress_parity.py [--n 40] [--seed 1]"""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fixtures as F  # noqa: E402
+import oracle_lib as O  # noqa: E402
+from uvaia_amd import capi  # noqa: E402
+
+
+def one(rng, k):
+    nchar = rng.choice([61, 128, 333, 777, 1024, 2500, 4097])
+    nq = rng.choice([1, 3, 16, 17, 40, 64, 65, 100, 150, 257])
+    nref = rng.choice([70, 300, 1000, 2500])
+    acgt = rng.random() < 0.5
+    trim = rng.choice([0, 0, 7, min(230, nchar // 4)])
+    nbest = rng.choice([1, 2, 5, 13, 40])
+    pool = rng.choice([64, 97, 333, 1000, nref])
+    env = {"UVAIA_GPU_RARE_MAX": rng.choice([None, "0", "1", "3", "50"]), "UVAIA_GPU_SCAN_QBLOCK": rng.choice([None, "0", "1"]),
+           "UVAIA_GPU_SUBSLICE": rng.choice([None, "64", "256"]), "UVAIA_GPU_SUBSLICE_MINQ": rng.choice([None, "1"])}
+    for key, v in env.items():
+        if v is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = v
+    p_snp = rng.choice([0.002, 0.006, 0.02])
+    refs, root, cols = F.synth_alignment(nref, nchar, seed=1000 + k, p_snp=p_snp)
+    qs, _, _ = F.synth_alignment(nq, nchar, seed=5000 + k, root=root, poly_cols=cols, p_snp=p_snp)
+    if rng.random() < 0.4:          # N runs across the queries: no constant-and-complete column, pools stop mattering
+        qs = [bytearray(s) for s in qs]
+        for i, s in enumerate(qs[:max(1, nq // 2)]):
+            a = (i * 37) % max(1, nchar - 20)
+            s[a:a + 20] = b"N" * len(s[a:a + 20])
+        qs = [bytes(s) for s in qs]
+    desc = dict(nchar=nchar, nq=nq, nref=nref, acgt=acgt, trim=trim, nbest=nbest, pool=pool, p_snp=p_snp, **{k_: v for k_, v in env.items() if v is not None})
+    q = O.Query(qs, ["q%d" % i for i in range(nq)], acgt=acgt, trim=trim, ambig_q=1.0)
+    if q.ntax < 1:
+        return desc, True
+    gold = O.search(q, refs, ["r%d" % i for i in range(nref)], pool=pool, nbest=nbest, ambig_r=1.0)
+    want = [[(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(q.ntax)]
+    ok = True
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool) as eng:           # streamed
+        ent = [eng.push(refs[a:a + pool]) for a in range(0, nref, pool)]
+        n, T, sc, od = eng.drain()
+        ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(np.concatenate(ent))[0]) == list(gold.saved)
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool) as eng:           # resident
+        eng.db_append(refs)
+        e2 = eng.search_resident(pool)
+        n, T, sc, od = eng.drain()
+        ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e2)[0]) == list(gold.saved)
+    desc["cons"] = len(q.idx_c) > 0
+    return desc, bool(ok)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    bad = 0
+    for k in range(a.n):
+        desc, ok = one(rng, k + 100 * a.seed)
+        print(("ok   " if ok else "FAIL ") + str(desc), flush=True)
+        bad += not ok
+    print("%d of %d configurations failed" % (bad, a.n))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -188,28 +188,58 @@ main (int argc, char **argv)
     if (!db) biomcmc_error ("%s", msg);
     if ((int) db->h.nchar != query->aln->nchar) biomcmc_error ("packed database %s has %u sites but query sequences have %d sites; all sequences must be aligned", o.packed, db->h.nchar, query->aln->nchar);
     if (db->h.ref_ambiguity != o.ambig_r) biomcmc_error ("packed database %s was filtered with -A %g: use the same value (its filter cannot be undone or tightened here)", o.packed, db->h.ref_ambiguity);
-    if (o.exclude_self) biomcmc_error ("-x is not available with --packed in this version: the name filter changes which references share a batch");
     if (db->h.side_row_ints != (uint32_t) uvaia_gpu_db_side_row_ints () || db->h.tile_bytes != uvaia_gpu_db_tile_bytes (gpu)) biomcmc_error ("packed database %s does not match this engine's tile layout", o.packed);
-    const uint64_t n = db->h.n_ref, chunk_tiles = 256;
-    if (uvaia_gpu_db_reserve (gpu, (size_t) n)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
-    for (uint64_t t = 0; t < db->h.n_tiles; t += chunk_tiles) {
-      const uint64_t nt = (db->h.n_tiles - t < chunk_tiles) ? db->h.n_tiles - t : chunk_tiles;
-      const uint64_t first = t * 64, cnt = (first + nt * 64 > n) ? n - first : nt * 64;
-      if (uvaia_gpu_db_append_packed (gpu, uvdb_tile_planes (db, t), db->non_n + first, uvdb_tile_side_rows (db, t), (int) cnt)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    const uint64_t n_all = db->h.n_ref, chunk_tiles = 256;
+    /* -x: references named like a query leave the stream (src/nearest.c:257-262); the others move up, lane by lane */
+    uint64_t *keep = NULL, n = n_all;
+    if (o.exclude_self) {
+      keep = (uint64_t *) biomcmc_malloc ((size_t) (n_all ? n_all : 1) * sizeof (uint64_t));
+      n = 0;
+      for (uint64_t i = 0; i < n_all; i++) { if (lookup_hashtable (query->aln->taxlabel_hash, (char *) uvdb_name (db, i)) > -1) same_name++; else keep[n++] = i; }
+      if (n == n_all) { free (keep); keep = NULL; }
     }
-    count = (int) n;
-    fprintf (stderr, "Loaded %d packed sequences from %s in %.3lf secs;\n", count, o.packed, biomcmc_update_elapsed_time (time0));
+    if (uvaia_gpu_db_reserve (gpu, (size_t) (n ? n : 1))) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    if (!keep) {
+      for (uint64_t t = 0; t < db->h.n_tiles; t += chunk_tiles) {
+        const uint64_t nt = (db->h.n_tiles - t < chunk_tiles) ? db->h.n_tiles - t : chunk_tiles;
+        const uint64_t first = t * 64, cnt = (first + nt * 64 > n) ? n - first : nt * 64;
+        if (uvaia_gpu_db_append_packed (gpu, uvdb_tile_planes (db, t), db->non_n + first, uvdb_tile_side_rows (db, t), (int) cnt)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+      }
+    } else {
+      const size_t tb = (size_t) db->h.tile_bytes, row = (size_t) db->h.side_row_ints, pieces = tb / (64 * 16);   /* 16-byte pieces per lane */
+      unsigned char *planes = (unsigned char *) biomcmc_malloc (chunk_tiles * tb);
+      int32_t *nn = (int32_t *) biomcmc_malloc (chunk_tiles * 64 * sizeof (int32_t)), *side = (int32_t *) biomcmc_malloc (chunk_tiles * 64 * row * sizeof (int32_t));
+      for (uint64_t s0 = 0; s0 < n; s0 += chunk_tiles * 64) {
+        const uint64_t cnt = (n - s0 < chunk_tiles * 64) ? n - s0 : chunk_tiles * 64;
+        memset (planes, 0, chunk_tiles * tb); memset (nn, 0, chunk_tiles * 64 * sizeof (int32_t)); memset (side, 0, chunk_tiles * 64 * row * sizeof (int32_t));
+#pragma omp parallel for schedule(static)
+        for (uint64_t k = 0; k < cnt; k++) {
+          const uint64_t r = keep[s0 + k];
+          const unsigned char *src = (const unsigned char *) uvdb_tile_planes (db, r / 64) + (r % 64) * 16;
+          unsigned char *dst = planes + (k / 64) * tb + (k % 64) * 16;
+          for (size_t p = 0; p < pieces; p++) memcpy (dst + p * 1024, src + p * 1024, 16);
+          nn[k] = db->non_n[r];
+          memcpy (side + k * row, uvdb_tile_side_rows (db, r / 64) + (r % 64) * row, row * sizeof (int32_t));
+        }
+        if (uvaia_gpu_db_append_packed (gpu, planes, nn, side, (int) cnt)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+      }
+      free (planes); free (nn); free (side);
+    }
+    count = (int) n_all;
+    fprintf (stderr, "Loaded %d packed sequences from %s in %.3lf secs;\n", (int) n, o.packed, biomcmc_update_elapsed_time (time0));
     uint8_t *ent = (uint8_t *) biomcmc_malloc ((size_t) (n ? n : 1));
     if (n && uvaia_gpu_search_resident (gpu, (size_t) o.pool, 0, ent)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
     char *text = (char *) biomcmc_malloc ((size_t) query->aln->nchar + 1);
     for (uint64_t i = 0; i < n; i++) if (ent[i]) {     /* dump every sequence that entered some heap, in stream order */
+      const uint64_t r = keep ? keep[i] : i;
       n_output++;
-      uvdb_unpack_reference (db, i, text);
-      write_fasta_record (outstream, uvdb_name (db, i), text);
-      name_table_set (&names, (int64_t) i, uvdb_name (db, i));
+      uvdb_unpack_reference (db, r, text);
+      write_fasta_record (outstream, uvdb_name (db, r), text);
+      name_table_set (&names, (int64_t) i, uvdb_name (db, r));
     }
-    free (text); free (ent);
+    free (text); free (ent); free (keep);
     fprintf (stderr, "Total of %d sequences searched; %d saved sequences include closest neighbours and intermediate. %.3lf secs elapsed. \n", count, n_output, biomcmc_update_elapsed_time (time1));
+    if (o.exclude_self) fprintf (stderr, " %d reference sequences already present in query alignment (based on name only).\n", same_name);
     uvdb_close_reader (db);
   }
   for (int j = 0; j < o.n_ref; j++) {

@@ -236,6 +236,7 @@ biomcmc_open_compress (const char *path, const char *mode)
     if (!tool) { free (quoted); free (cmd); biomcmc_error ("cannot open file %s for reading", path); }
     if (*tool) { sprintf (cmd, "%s %s", tool, quoted); fc->fp = popen (cmd, "r"); fc->piped = 1; }
     else fc->fp = fopen (path, "r");
+    if (fc->fp) setvbuf (fc->fp, NULL, _IOFBF, 1u << 22);     /* 30 kb lines: the default 4 KiB buffer costs a refill per eighth of a line */
   } else {
     const char *tool = NULL;   /* the reference tries xz, then bz2, then gz, then plain text (src/nearest.c:234) */
     if (ends_with (path, ".xz") && tool_available ("xz")) tool = "xz -T0 -c";   /* all cores: the dump of a large search is hundreds of MB of text */

@@ -24,14 +24,35 @@ promote_pending_name (readfasta_t r)
   r->next_name = NULL;
 }
 
+/* one pass over a sequence line: white space dropped, letters upper-cased (what remove_space_from_string + uppercase_string do
+   in two), appended to the record; returns the number of characters appended */
+static size_t
+append_sequence_line (readfasta_t r, const char *line, size_t len)
+{
+  static unsigned char map[256];     /* 0 = white space (dropped), else the character to store */
+  static int ready = 0;
+  if (!ready) {
+    for (int c = 0; c < 256; c++) map[c] = (unsigned char) ((c == ' ' || (c >= '\t' && c <= '\r')) ? 0 : ((c >= 'a' && c <= 'z') ? c - 32 : c));
+    ready = 1;
+  }
+  r->seq = (char *) biomcmc_realloc (r->seq, r->seqlength + len + 1);
+  char *w = r->seq + r->seqlength;
+  for (size_t i = 0; i < len; i++) { const unsigned char m = map[(unsigned char) line[i]]; *w = (char) m; w += (m != 0); }
+  *w = '\0';
+  const size_t added = (size_t) (w - (r->seq + r->seqlength));
+  r->seqlength += added;
+  return added;
+}
+
 int
 readfasta_next (readfasta_t r)
 {
   if (!r->seqfile) return -1;
-  while (biomcmc_getline_compress (&r->line_read, &r->linelength, r->seqfile) != -1) {
+  int got;
+  while ((got = biomcmc_getline_compress (&r->line_read, &r->linelength, r->seqfile)) != -1) {
     char *line = r->line_read;
-    if (!nonempty_fasta_line (line)) continue;
-    char *header = strchr (line, '>');
+    if (!nonempty_fasta_line (line)) continue;             /* stops at the first character that is not white space */
+    char *header = (char *) memchr (line, '>', (size_t) got);
     if (header) {              /* a header closes the record being assembled (if any) */
       header++;
       r->newseq = true;
@@ -43,11 +64,7 @@ readfasta_next (readfasta_t r)
       continue;
     }
     if (r->newseq) { free (r->seq); r->seq = NULL; r->seqlength = 0; r->newseq = false; }
-    uppercase_string (remove_space_from_string (line));
-    size_t l = strlen (line);
-    r->seq = (char *) biomcmc_realloc (r->seq, r->seqlength + l + 1);
-    memcpy (r->seq + r->seqlength, line, l + 1);
-    r->seqlength += l;
+    append_sequence_line (r, line, (size_t) got);
   }
   biomcmc_close_compress (r->seqfile);
   r->seqfile = NULL;

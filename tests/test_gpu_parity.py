@@ -255,6 +255,25 @@ def test_odd_shapes_with_enough_queries_for_every_path(acgt, nchar, nq, nref, se
     _assert_same_search(q, refs, nref, 3)
 
 
+def test_long_alignments_take_the_wide_counter_scan():
+    """More than ~49 000 columns do not fit the 16-bit counter halves of the default scan: the engine switches to the
+    four-counter scan by itself; results as the oracle's."""
+    nchar = 50017
+    refs, root, cols = F.synth_alignment(150, nchar, seed=31, p_snp=0.002)
+    qs, _, _ = F.synth_alignment(5, nchar, seed=32, root=root, poly_cols=cols, p_snp=0.002)
+    for acgt in (False, True):
+        _assert_same_search(O.Query(qs, _names(len(qs), "q"), acgt=acgt), refs, 64, 4)
+
+
+@pytest.mark.parametrize("variant", ["sgpr", "lds"])
+@pytest.mark.parametrize("acgt", [False, True])
+def test_earlier_scan_variants_still_agree(synth, monkeypatch, variant, acgt):
+    """UVAIA_GPU_SCAN=sgpr|lds: the two-counter scans of the kernel history stay usable for A/B runs."""
+    monkeypatch.setenv("UVAIA_GPU_SCAN", variant)
+    refs, qs = synth
+    _assert_same_search(O.Query(qs, _names(len(qs), "q"), acgt=acgt), refs[:400], 100, 6)
+
+
 def test_query_tile_sizes_agree(synth):
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"))

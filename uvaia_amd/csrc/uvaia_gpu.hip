@@ -1996,6 +1996,9 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   if (env_scan) c->scan_variant = (strcmp(env_scan, "lds") == 0) ? 1 : (strcmp(env_scan, "sgpr") == 0) ? 0 : 2;
   const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
   c->fullscan = env_full && atoi(env_full) != 0;
+  // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
+  // four-counter scan instead (32-bit counts, same results, slower)
+  if (c->nchar > 49000) c->fullscan = true;
   c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
   c->max_pool = max_pool; c->pool_pad = ((max_pool + 63) / 64) * 64 + 64;
   c->pitch = ((size_t)c->nchar + 63) / 64 * 64;

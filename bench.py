@@ -132,6 +132,7 @@ def main():
                                   lambda nb: ring.TorchStateBuffer(nb, "cuda" if on_gpu else "cpu"))
         eng.sync()
 
+    step()                             # setup, not a warmup step: the engine sizes its counter buffers on the first search
     for _ in range(args.warmup):
         step()
     eng.scan_stats(reset=True)

@@ -281,8 +281,8 @@ def main():
                        "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2),
                        "query_prepare_s": round(t_q1 - t_q0, 2), "engine_open_s": round(t_q2 - t_q1, 2)},
             "roofline": roofline,
-            "replay": {"admissions_per_step": admitted // max(1, args.steps + args.warmup), "on_demand_per_step": demanded // max(1, args.steps + args.warmup),
-                       "dense_rescans_per_step": dense_rescans // max(1, args.steps + args.warmup)},
+            "replay": {"admissions_per_step": admitted // max(1, args.steps + args.warmup + 1), "on_demand_per_step": demanded // max(1, args.steps + args.warmup + 1),
+                       "dense_rescans_per_step": dense_rescans // max(1, args.steps + args.warmup + 1)},
             "cpu_baseline": cpu,
             "parity_check_on_sample": parity,
         }

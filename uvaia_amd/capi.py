@@ -46,9 +46,9 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
-    src = os.path.join(_HERE, "csrc", "uvaia_gpu.hip")
-    hdr = os.path.join(ROOT, "include", "uvaia_gpu.h")
-    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))] + [os.path.join(ROOT, "include", "uvaia_gpu.h")]
+    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(f) for f in srcs):
         return _LIB
     subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
     return _LIB

@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N",
                     help="single process: do the work of rank 0 of N query shards (whole stream of N x --refs references, 1/N of the queries) "
                          "to measure the per-rank time of an N-GPU run on one GPU; the line is marked as emulated")
+    ap.add_argument("--search-only", action="store_true",
+                    help="leave the per-query-set planes of the resident database as the load built them (the timed step then "
+                         "holds scan + replay only); by default every step rebuilds them first")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
     return ap.parse_args()
 
@@ -121,8 +124,13 @@ def main():
     allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons and dist is not None) else None
 
     # ---- timed region
-    def step():
+    # One step = everything one search of the resident database costs for this query set: the planes derived from the packed
+    # records for the query set (built by the appends while loading; rebuilt here so that the step holds them), the pair scan,
+    # the consensus pre-score where it applies, and the ordered replay into the heaps.
+    def step(derive=not args.search_only):
         eng.reset()
+        if derive:
+            eng.db_rederive()
         if world == 1 and not emu:
             eng.search_resident(pool, ordinal0=0, want_entered=False)
         elif shard_mode:   # no data-path exchange (one all-reduced int per pool if the query set has complete constant columns)
@@ -151,6 +159,20 @@ def main():
     gc.enable()
     scan_ms, scan_launches, scan_bytes = eng.scan_stats(reset=True)
     admitted, demanded, dense_rescans = eng.replay_stats(reset=True)
+    # the two parts of a step on their own (untimed for `value`): derived planes only, scan + replay only
+    gc.disable()
+    t_d = time.perf_counter()
+    for _ in range(args.steps):
+        eng.db_rederive()
+        eng.sync()
+    derive_ms = 1e3 * (time.perf_counter() - t_d) / max(1, args.steps)
+    t_d = time.perf_counter()
+    for _ in range(args.steps):
+        step(derive=False)
+    search_only_ms = 1e3 * (time.perf_counter() - t_d) / max(1, args.steps)
+    gc.enable()
+    eng.scan_stats(reset=True)
+    eng.replay_stats(reset=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,6 +302,9 @@ def main():
                        "queries": pq.ntax, "refs_per_gpu": args.refs, "nchar": args.nchar, "nbest": args.nbest, "pool": pool,
                        "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2),
                        "query_prepare_s": round(t_q1 - t_q0, 2), "engine_open_s": round(t_q2 - t_q1, 2)},
+            "step_parts": {"includes_derived_planes": not args.search_only, "derived_planes_ms": round(derive_ms, 3), "scan_and_replay_ms": round(search_only_ms, 3),
+                           "note": "a step = planes derived from the resident packed records for this query set (uvaia_gpu_db_rederive) + pair scan + ordered replay; "
+                                   "the two parts timed on their own after the timed region"},
             "roofline": roofline,
             "replay": {"admissions_per_step": admitted // max(1, args.steps + args.warmup + 1), "on_demand_per_step": demanded // max(1, args.steps + args.warmup + 1),
                        "dense_rescans_per_step": dense_rescans // max(1, args.steps + args.warmup + 1)},

@@ -171,6 +171,11 @@ int uvaia_gpu_search_resident_pool (uvaia_gpu_ctx *ctx, size_t first, size_t n, 
  *   append_packed: n_ref references = ceil(n_ref/64) tiles; the database must hold a whole number of tiles before the call */
 size_t uvaia_gpu_db_tile_bytes (const uvaia_gpu_ctx *ctx);
 int    uvaia_gpu_db_clear (uvaia_gpu_ctx *ctx);                      /* empties the resident database, keeps its capacity */
+/* Rebuilds, for every resident reference, the planes the scan reads for the open query set (the appends build them for the rows
+ * they add): the per-reference share of the work that depends on the query set (the reference does it implicitly, its loops
+ * read the raw sequences through idx_c / idx_m / idx, src/nearest.c:428-510).  Asynchronous; later searches wait for it.  Call
+ * between searches (after uvaia_gpu_sync), e.g. to time a search of a resident database together with this work. */
+int    uvaia_gpu_db_rederive (uvaia_gpu_ctx *ctx);
 int    uvaia_gpu_db_side_row_ints (void);
 int    uvaia_gpu_db_export (uvaia_gpu_ctx *ctx, size_t first_tile, size_t n_tiles, void *planes, int *non_n, int *side_rows);
 int    uvaia_gpu_db_append_packed (uvaia_gpu_ctx *ctx, const void *planes, const int *non_n, const int *side_rows, int n_ref);

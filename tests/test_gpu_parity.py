@@ -255,6 +255,34 @@ def test_odd_shapes_with_enough_queries_for_every_path(acgt, nchar, nq, nref, se
     _assert_same_search(q, refs, nref, 3)
 
 
+@pytest.mark.parametrize("acgt", [False, True])
+def test_separate_derive_kernels_agree_and_rederive_is_idempotent(acgt, monkeypatch):
+    """The planes the scan reads are built by one fused kernel (default) or by the three kernels it replaced
+    (UVAIA_GPU_DERIVE_SPLIT=1): same heaps either way, and rebuilding them on a resident database changes nothing."""
+    refs, root, cols = F.synth_alignment(700, 3001, seed=41)
+    qs, _, _ = F.synth_alignment(90, 3001, seed=141, root=root, poly_cols=cols)
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+    out = []
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("UVAIA_GPU_DERIVE_SPLIT", "1")
+        with capi.Engine.from_query(q, nbest=6, max_pool=256) as eng:
+            eng.db_reserve(len(refs))
+            eng.db_append(refs[:333])
+            eng.db_append(refs[333:])
+            ent = eng.search_resident(200)
+            n, T, sc, od = eng.drain()
+            out.append((capi.finalise_heaps(n, sc, od), list(T), ent.copy()))
+            eng.reset()
+            eng.db_rederive()
+            ent2 = eng.search_resident(200)
+            n, T, sc, od = eng.drain()
+            assert (capi.finalise_heaps(n, sc, od), list(T)) == out[-1][:2] and np.array_equal(ent2, out[-1][2])
+    assert out[0][:2] == out[1][:2] and np.array_equal(out[0][2], out[1][2])
+    gold = O.search(q, refs, _names(len(refs)), pool=200, nbest=6, ambig_r=1.0)
+    assert out[0][0] == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows] and out[0][1] == gold.final_T
+
+
 def test_long_alignments_take_the_wide_counter_scan():
     """More than ~49 000 columns do not fit the 16-bit counter halves of the default scan: the engine switches to the
     four-counter scan by itself; results as the oracle's."""

@@ -19,7 +19,7 @@ SYMBOLS = [
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
     "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
-    "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear",
+    "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear", "uvaia_gpu_db_rederive",
     "uvaia_gpu_set_active_queries", "uvaia_gpu_max_tolerance", "uvaia_gpu_search_resident_pool",
 ]
 
@@ -106,6 +106,7 @@ def load_library():
         "uvaia_gpu_search_resident_pool": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int64, C.c_int]),
         "uvaia_gpu_db_tile_bytes": (C.c_size_t, [vp]),
         "uvaia_gpu_db_clear": (C.c_int, [vp]),
+        "uvaia_gpu_db_rederive": (C.c_int, [vp]),
         "uvaia_gpu_db_side_row_ints": (C.c_int, []),
         "uvaia_gpu_db_export": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_void_p, pi, pi]),
         "uvaia_gpu_db_append_packed": (C.c_int, [vp, C.c_void_p, pi, pi, C.c_int]),
@@ -241,6 +242,10 @@ class Engine:
 
     def db_clear(self):
         self._chk(self.L.uvaia_gpu_db_clear(self.ctx))
+
+    def db_rederive(self):
+        """Rebuild the query-set-dependent planes of the whole resident database (asynchronous)."""
+        self._chk(self.L.uvaia_gpu_db_rederive(self.ctx))
 
     def db_export(self, first_tile=0, n_tiles=None):
         """Packed interchange form of the resident database: (planes uint8 [n_tiles, tile_bytes], non_n int32 [n_tiles*64],

@@ -72,7 +72,7 @@ struct uvaia_gpu_ctx {
   unsigned scan_rr = 0;
   int scan_nstreams = 1;                  // streams consecutive scans alternate over (set per search from the launch size)
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
-  hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
+  hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {}, derive_done = nullptr;
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
   size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
   int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
@@ -99,6 +99,8 @@ struct uvaia_gpu_ctx {
   int NP = 0, NP4 = 0;           // polymorphic columns counted densely
   int NR = 0, NR4 = 0, rare_max = -1;   // "rare" columns: all but <= rare_max queries carry the same base; sparse (items), groups follow the dense ones
   uint32_t *d_rmask = nullptr;   // [W4*4] mask of the rare columns
+  int *d_split = nullptr;        // derive_all_kernel: w4 range and first gathered bit of each of its four waves
+  bool derive_fused = true;      // UVAIA_GPU_DERIVE_SPLIT=1: the three separate kernels instead (A/B, tests)
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
@@ -363,7 +365,10 @@ int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref)
   uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
   const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
   const int nblk = (int)(t1 - t0 + 1);
-  if (c->acgt) {
+  if (c->derive_fused && c->d_split) {
+    if (c->acgt) hipLaunchKernelGGL((derive_all_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
+    else         hipLaunchKernelGGL((derive_all_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
+  } else if (c->acgt) {
     hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
     if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
     if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
@@ -423,13 +428,14 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
+  if (c->derive_done) hipEventDestroy(c->derive_done);
   if (c->scan_stream) hipStreamDestroy(c->scan_stream);
   for (int i = 1; i < 3; i++) if (c->scan_streams[i]) hipStreamDestroy(c->scan_streams[i]);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -479,6 +485,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     c->scan_streams[0] = c->scan_stream;
     for (int i = 1; i < 3; i++) OPENCHK(hipStreamCreateWithPriority(&c->scan_streams[i], hipStreamNonBlocking, prio_least));
     for (int i = 0; i < NBUF; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
+    OPENCHK(hipEventCreateWithFlags(&c->derive_done, hipEventDisableTiming));
   }
   uint8_t code_tab[256]; fill_code_table(code_tab);
   OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
@@ -649,6 +656,17 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       OPENCHK(hipMalloc(&c->d_cls, cls.size() * 4)); OPENCHK(hipMemcpy(c->d_cls, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_qrare, qrare.size() * 4)); OPENCHK(hipMemcpy(c->d_qrare, qrare.data(), qrare.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_rmask, rmask.size() * 4)); OPENCHK(hipMemcpy(c->d_rmask, rmask.data(), rmask.size() * 4, hipMemcpyHostToDevice));
+      {   // derive_all_kernel: word groups per wave and the bit positions its gathered columns start at
+        int split[15];
+        for (int v = 0; v <= 4; v++) split[v] = (int)((long long)c->W4 * v / 4);
+        for (int v = 0; v <= 4; v++) {
+          int nd = 0, nr = 0;
+          for (int w = 0; w < split[v] * 4; w++) { nd += __builtin_popcount(cls[(size_t)w * 4 + 3]); nr += __builtin_popcount(rmask[(size_t)w]); }
+          split[5 + v] = nd; split[10 + v] = nr;
+        }
+        OPENCHK(hipMalloc(&c->d_split, sizeof split)); OPENCHK(hipMemcpy(c->d_split, split, sizeof split, hipMemcpyHostToDevice));
+        c->derive_fused = getenv("UVAIA_GPU_DERIVE_SPLIT") == nullptr;
+      }
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
       std::vector<uint32_t> strm, sdir((size_t)(c->nq_pad / 16) * 2, 0u);
@@ -901,6 +919,21 @@ int uvaia_gpu_db_append_block(uvaia_gpu_ctx *c, const char *rows, size_t pitch, 
 }
 
 size_t uvaia_gpu_db_size(const uvaia_gpu_ctx *c) { return c ? c->db_n : 0; }
+
+int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
+{ // the reference-side work a query set costs on a database that is already resident: E/V/grp planes and gathered columns of
+  // every tile for the open query set.  Appends do this for the rows they add; a caller that times "one search of a resident
+  // database" without its appends calls this first so that the figure holds everything that depends on the query set.
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (!c->d_db || !c->db_n || c->fullscan) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (size_t a = 0; a < c->db_n; a += (size_t)1 << 30) {      // derive_rows counts references in an int
+    int rc = derive_rows(c, c->d_db, (long long)a, (int)std::min<size_t>((size_t)1 << 30, c->db_n - a)); if (rc) return rc;
+  }
+  HIPCHK(c, hipEventRecord(c->derive_done, c->stream));
+  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamWaitEvent(c->scan_streams[i_], c->derive_done, 0));
+  return 0;
+}
 
 int uvaia_gpu_db_clear(uvaia_gpu_ctx *c)
 {

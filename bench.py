@@ -303,6 +303,9 @@ def main():
                        "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2),
                        "query_prepare_s": round(t_q1 - t_q0, 2), "engine_open_s": round(t_q2 - t_q1, 2)},
             "step_parts": {"includes_derived_planes": not args.search_only, "derived_planes_ms": round(derive_ms, 3), "scan_and_replay_ms": round(search_only_ms, 3),
+                           "derived_planes_kernel": {"kernel": "derive_all_kernel", "bound": "hbm", "read_bytes_per_ref": bytes_per_ref, "written_bytes_per_ref": eng.derived_bytes_per_ref(),
+                                                     "achieved": round(local_refs * (bytes_per_ref + eng.derived_bytes_per_ref()) / (derive_ms * 1e-3) / 1e9, 1) if derive_ms > 0 else None,
+                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s (reads + writes, host-timed over its launches)"},
                            "note": "a step = planes derived from the resident packed records for this query set (uvaia_gpu_db_rederive) + pair scan + ordered replay; "
                                    "the two parts timed on their own after the timed region"},
             "roofline": roofline,

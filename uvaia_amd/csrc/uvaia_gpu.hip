@@ -72,7 +72,13 @@ struct uvaia_gpu_ctx {
   unsigned scan_rr = 0;
   int scan_nstreams = 1;                  // streams consecutive scans alternate over (set per search from the launch size)
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
-  hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {}, derive_done = nullptr;
+  hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
+  // uvaia_gpu_db_rederive: chunks of tiles rebuilt on their own stream; a scan waits for the chunks its slice touches
+  struct DeriveChunk { long long t0, t1; hipEvent_t done; };
+  hipStream_t derive_stream = nullptr;
+  std::vector<DeriveChunk> derive_chunks;
+  hipEvent_t derive_fence[4] = {};
+  size_t derive_pending = 0;          // chunks of the last rederive a scan may still have to wait for
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
   size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
   int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
@@ -356,8 +362,9 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
 }
 
 // planes derived for the open query set (column-compressed scan) for the whole tiles that hold slots slot0 .. slot0 + n_ref - 1
-int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref)
+int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipStream_t st = nullptr)
 {
+  if (!st) st = c->stream;
   if (c->fullscan || n_ref <= 0) return 0;
   const bool is_db = (tiles == c->d_db);
   uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
@@ -366,18 +373,25 @@ int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref)
   const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
   const int nblk = (int)(t1 - t0 + 1);
   if (c->derive_fused && c->d_split) {
-    if (c->acgt) hipLaunchKernelGGL((derive_all_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
-    else         hipLaunchKernelGGL((derive_all_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
+    if (c->acgt) hipLaunchKernelGGL((derive_all_kernel<true>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
+    else         hipLaunchKernelGGL((derive_all_kernel<false>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
   } else if (c->acgt) {
-    hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
-    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
+    hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
+    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
+    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
   } else {
-    hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, c->stream, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
-    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, c->stream, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
+    hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
+    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
+    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
   }
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// a rebuild of the derived planes still in flight (uvaia_gpu_db_rederive) must end before the database changes
+static int settle_derive(uvaia_gpu_ctx *c)
+{
+  if (c->derive_pending) { HIPCHK(c, hipStreamSynchronize(c->derive_stream)); c->derive_pending = 0; }
   return 0;
 }
 
@@ -435,7 +449,9 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (c->h_stage) hipHostFree(c->h_stage);
   for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
-  if (c->derive_done) hipEventDestroy(c->derive_done);
+  if (c->derive_stream) { hipStreamSynchronize(c->derive_stream); hipStreamDestroy(c->derive_stream); }
+  for (auto &d : c->derive_chunks) hipEventDestroy(d.done);
+  for (int i = 0; i < 4; i++) if (c->derive_fence[i]) hipEventDestroy(c->derive_fence[i]);
   if (c->scan_stream) hipStreamDestroy(c->scan_stream);
   for (int i = 1; i < 3; i++) if (c->scan_streams[i]) hipStreamDestroy(c->scan_streams[i]);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -485,7 +501,12 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     c->scan_streams[0] = c->scan_stream;
     for (int i = 1; i < 3; i++) OPENCHK(hipStreamCreateWithPriority(&c->scan_streams[i], hipStreamNonBlocking, prio_least));
     for (int i = 0; i < NBUF; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
-    OPENCHK(hipEventCreateWithFlags(&c->derive_done, hipEventDisableTiming));
+    {   // between the scan (lowest) and the replay (highest): its blocks take the slots scan blocks free, ahead of the next scan blocks
+      const char *ep = getenv("UVAIA_GPU_DERIVE_PRIO");
+      const int mid = (prio_least + prio_greatest) / 2;
+      const int pr = ep ? std::max(prio_greatest, std::min(prio_least, atoi(ep))) : mid;
+      OPENCHK(hipStreamCreateWithPriority(&c->derive_stream, hipStreamNonBlocking, pr));
+    }
   }
   uint8_t code_tab[256]; fill_code_table(code_tab);
   OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
@@ -821,6 +842,12 @@ size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
                                                 : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->need_g_groups * 4 + (size_t)(c->NP4 + c->need_r_groups) * 16 * 3;
 }
 
+size_t uvaia_gpu_derived_bytes_per_ref(const uvaia_gpu_ctx *c)
+{ // bytes per reference of the planes built for the open query set (E, V, group counts, gathered columns, total)
+  if (!c || c->fullscan) return 0;
+  return (size_t)c->W4 * 32 + (size_t)c->W4 * 4 + (size_t)(c->NP4 + c->NR4) * 48 + 4;
+}
+
 int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
 {
   if (!c) return UVAIA_GPU_EINVAL;
@@ -899,6 +926,7 @@ static int db_append_common(uvaia_gpu_ctx *c, const char *const *seq, const char
   if (!c) return UVAIA_GPU_EINVAL;
   if (n_ref < 0) return fail(c, UVAIA_GPU_EINVAL, "negative count");
   if (n_ref == 0) return 0;
+  { int rc = settle_derive(c); if (rc) return rc; }
   if (c->db_n + (size_t)n_ref > c->db_cap) {
     if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "database capacity %zu exceeded: call uvaia_gpu_db_reserve first", c->db_cap);
     int rc = uvaia_gpu_db_reserve(c, (size_t)n_ref); if (rc) return rc;
@@ -920,25 +948,11 @@ int uvaia_gpu_db_append_block(uvaia_gpu_ctx *c, const char *rows, size_t pitch, 
 
 size_t uvaia_gpu_db_size(const uvaia_gpu_ctx *c) { return c ? c->db_n : 0; }
 
-int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
-{ // the reference-side work a query set costs on a database that is already resident: E/V/grp planes and gathered columns of
-  // every tile for the open query set.  Appends do this for the rows they add; a caller that times "one search of a resident
-  // database" without its appends calls this first so that the figure holds everything that depends on the query set.
-  if (!c) return UVAIA_GPU_EINVAL;
-  if (!c->d_db || !c->db_n || c->fullscan) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
-  for (size_t a = 0; a < c->db_n; a += (size_t)1 << 30) {      // derive_rows counts references in an int
-    int rc = derive_rows(c, c->d_db, (long long)a, (int)std::min<size_t>((size_t)1 << 30, c->db_n - a)); if (rc) return rc;
-  }
-  HIPCHK(c, hipEventRecord(c->derive_done, c->stream));
-  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamWaitEvent(c->scan_streams[i_], c->derive_done, 0));
-  return 0;
-}
-
 int uvaia_gpu_db_clear(uvaia_gpu_ctx *c)
 {
   if (!c) return UVAIA_GPU_EINVAL;
   if (!c->d_db || !c->db_n) { c->db_n = 0; return 0; }
+  { int rc = settle_derive(c); if (rc) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   const size_t tiles = (c->db_n + 63) / 64;       // lanes past the last reference of a tile must read as zero planes
@@ -975,6 +989,7 @@ int uvaia_gpu_db_append_packed(uvaia_gpu_ctx *c, const void *planes, const int *
   if (n_ref == 0) return 0;
   if (!planes || !non_n || (!c->acgt && !side_rows)) return fail(c, UVAIA_GPU_EINVAL, "NULL packed arrays");
   if (c->db_n % 64) return fail(c, UVAIA_GPU_ESTATE, "packed tiles can only follow a whole number of tiles (database holds %zu references)", c->db_n);
+  { int rc = settle_derive(c); if (rc) return rc; }
   if (c->db_n + (size_t)n_ref > c->db_cap) {
     if (c->db_n) return fail(c, UVAIA_GPU_ESTATE, "database capacity %zu exceeded: call uvaia_gpu_db_reserve first", c->db_cap);
     int rc = uvaia_gpu_db_reserve(c, (size_t)n_ref); if (rc) return rc;
@@ -1030,6 +1045,46 @@ static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first
     for (size_t x = a; x < pe; x += each) subs.push_back({x, std::min(each, pe - x), x == a});
   }
   return subs;
+}
+
+int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
+{ // the reference-side work a query set costs on a database that is already resident: E/V/grp planes and gathered columns of
+  // every tile for the open query set.  Appends do this for the rows they add; a caller that times "one search of a resident
+  // database" without its appends calls this first so that the figure holds everything that depends on the query set.
+  // Issued on its own stream in the chunks the search will scan, one event each: the first slice's scan starts as soon as its
+  // chunk is done and the rest is rebuilt next to it (the rebuild is bound by HBM, the scan by instruction issue).
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (!c->d_db || !c->db_n || c->fullscan) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  {   // searches still in flight read the planes: the rebuild queues behind them
+    hipStream_t busy[4] = {c->stream, c->scan_streams[0], c->scan_streams[1], c->scan_streams[2]};
+    for (int i = 0; i < 4; i++) {
+      if (!busy[i]) continue;
+      if (!c->derive_fence[i]) HIPCHK(c, hipEventCreateWithFlags(&c->derive_fence[i], hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->derive_fence[i], busy[i]));
+      HIPCHK(c, hipStreamWaitEvent(c->derive_stream, c->derive_fence[i], 0));
+    }
+  }
+  std::vector<SubSlice> plan = plan_subslices(c, 0, c->db_n, c->max_pool);
+  if (getenv("UVAIA_GPU_DERIVE_ONE_LAUNCH")) plan.assign(1, SubSlice{0, c->db_n, true});
+  size_t k = 0;
+  long long t_done = 0;                 // slices that are not tile aligned share a tile: it belongs to the earlier chunk
+  for (const SubSlice &sl : plan) {
+    const long long t0 = std::max(t_done, (long long)(sl.first / 64)), t1 = (long long)((sl.first + sl.n + 63) / 64);
+    if (t0 >= t1) continue;
+    t_done = t1;
+    if (k == c->derive_chunks.size()) {
+      uvaia_gpu_ctx::DeriveChunk d{0, 0, nullptr};
+      HIPCHK(c, hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
+      c->derive_chunks.push_back(d);
+    }
+    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), c->derive_stream); if (rc) return rc;
+    c->derive_chunks[k].t0 = t0; c->derive_chunks[k].t1 = t1;
+    HIPCHK(c, hipEventRecord(c->derive_chunks[k].done, c->derive_stream));
+    k++;
+  }
+  c->derive_pending = k;
+  return 0;
 }
 
 // Two streams and a ring of NBUF counter buffers: the scan needs no state, so it runs up to NBUF-1 slices ahead of the replay.
@@ -1099,6 +1154,8 @@ int uvaia_gpu_search_resident_pool(uvaia_gpu_ctx *c, size_t first, size_t n, int
 int uvaia_gpu_sync(uvaia_gpu_ctx *c)
 {
   if (!c) return UVAIA_GPU_EINVAL;
+  if (c->derive_stream) HIPCHK(c, hipStreamSynchronize(c->derive_stream));
+  c->derive_pending = 0;
   for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return collect_events(c);
@@ -1222,6 +1279,10 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   }
   hipStream_t ss = c->scan_streams[c->scan_nstreams > 1 ? (c->scan_rr++ % c->scan_nstreams) : 0];
   if (c->replay_recorded[buf]) HIPCHK(c, hipStreamWaitEvent(ss, c->replay_done[buf], 0));   // the buffer's previous reader
+  for (size_t k = 0; k < c->derive_pending; k++) {                                          // planes being rebuilt (uvaia_gpu_db_rederive)
+    const auto &d = c->derive_chunks[k];
+    if (d.t0 < (long long)((first + n + 63) / 64) && d.t1 > (long long)(first / 64)) HIPCHK(c, hipStreamWaitEvent(ss, d.done, 0));
+  }
   const long long tf = (long long)(first / 64);
   const int n_tiles = n ? (int)((first + n + 63) / 64 - first / 64) : 0;
   c->slice_tf[buf] = tf; c->slice_tiles[buf] = n_tiles;

@@ -135,6 +135,14 @@ int uvaia_gpu_entered_flags (uvaia_gpu_ctx *ctx, uint8_t *out, int clear);   /* 
  * cq->mindist[c]; the caller keeps sequence i iff mindist[i] <= radius-1 (src/ball.c:255). */
 int uvaia_gpu_ball (uvaia_gpu_ctx *ctx, const char *const *seq, int n_ref, int radius, int *mindist);
 
+/* Query preprocessing: the O(Q^2) test of exclude_redundant_query_sequences (src/fastaseq.c:797-841, the
+ * call at :806-808).  For each of n_seq sequences (<= max_pool) and each query q of the open set,
+ *   out[i * n_query + q] = 1  when quick_pairwise_score_truncated_idx_indelcheck (default; src/fastaseq.c:562-574) or
+ *                             quick_pairwise_score_acgt (--acgt; :576-583) with maxdist 1 over query->idx would return 0,
+ * i.e. no polymorphic column where both are valid (--acgt: both ACGT) and differ; 0 otherwise.  Handing in the query
+ * sequences themselves gives the whole pair matrix; the host then walks it in the reference's order. */
+int uvaia_gpu_agree_on_polymorphic (uvaia_gpu_ctx *ctx, const char *const *seq, int n_seq, uint8_t *out);
+
 /* ---- introspection used by tests and bench.py ---- */
 /* untruncated pair scores of the last batch: out[(i*n_query+q)*6 + s] = the score[] vector src/nearest.c:499-501
  * (or :464-469 with --acgt) assembles for (reference i of the batch, query q) when nothing is truncated. */

@@ -1,0 +1,78 @@
+"""Query preprocessing on the device: the O(Q^2) pair test of exclude_redundant_query_sequences
+(src/fastaseq.c:797-841) as uvaia_gpu_agree_on_polymorphic, and the host walk over its matrix, against the host-only loop and
+the oracle."""
+import numpy as np
+import pytest
+
+import fixtures as F
+import oracle_lib as O
+from uvaia_amd import capi, hostlib as H
+
+pytestmark = pytest.mark.gpu
+
+INVALID = np.frombuffer(b"NX-?O.", dtype=np.uint8)
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _redundant_set(n_base, nchar, seed):
+    base, root, cols = F.synth_alignment(n_base, nchar, seed=seed, p_snp=0.004)
+    rng = np.random.default_rng(seed + 1)
+    qs = []
+    for s in base:
+        qs.append(s)
+        t = bytearray(s)
+        a, ln = int(rng.integers(0, nchar - 100)), int(rng.integers(1, 90))
+        t[a:a + ln] = b"N" * ln
+        qs.append(bytes(t))                # less resolved copy
+        if rng.random() < 0.5:
+            qs.append(s)                   # exact duplicate
+    return qs, ["q%d" % i for i in range(len(qs))]
+
+
+def _agree_reference(q, seqs, acgt):
+    """numpy restatement of quick_pairwise_score_truncated_idx_indelcheck / quick_pairwise_score_acgt == 0 (maxdist 1)."""
+    a = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), -1)[:, q.idx]
+    b = np.frombuffer(b"".join(q.seqs), dtype=np.uint8).reshape(q.ntax, -1)[:, q.idx]
+    ok_a = np.isin(a, ACGT) if acgt else ~np.isin(a, INVALID)
+    ok_b = np.isin(b, ACGT) if acgt else ~np.isin(b, INVALID)
+    out = np.zeros((len(seqs), q.ntax), dtype=np.uint8)
+    for i in range(len(seqs)):
+        out[i] = ~np.any(ok_a[i][None, :] & ok_b & (a[i][None, :] != b), axis=1)
+    return out
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("trim", [0, 150])
+def test_agreement_matrix(acgt, trim):
+    qs, names = _redundant_set(30, 2300, seed=5)
+    q = O.Query(qs, names, acgt=acgt, trim=trim)
+    other, _, _ = F.synth_alignment(70, 2300, seed=77)
+    with capi.Engine.from_query(q, nbest=1, max_pool=256) as eng:
+        for batch in (q.seqs, other, q.seqs[:65]):
+            got = eng.agree_on_polymorphic(batch)
+            assert np.array_equal(got, _agree_reference(q, batch, acgt))
+    assert got[:, :65].diagonal().all()            # a sequence agrees with itself
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("keep,ball", [(True, False), (False, True), (True, True)])
+def test_pruning_on_device_equals_host_and_oracle(monkeypatch, acgt, keep, ball):
+    qs, names = _redundant_set(40, 1800, seed=8)
+    monkeypatch.setenv("UVAIA_PRUNE", "host")
+    host = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    monkeypatch.setenv("UVAIA_PRUNE", "device")
+    dev = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    gold = O.Query(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    assert dev.names == host.names == gold.names and dev.seqs == gold.seqs
+    assert dev.ntax < len(qs)
+    for f in ("idx_c", "idx_m", "idx"):
+        assert np.array_equal(getattr(dev, f), getattr(gold, f)), f
+
+
+def test_large_query_sets_prune_on_the_device_by_default():
+    """From 512 queries on the pair matrix comes from the device without any switch; batches of 2 048 sequences."""
+    qs, names = _redundant_set(260, 900, seed=21)
+    assert len(qs) >= 512
+    dev = H.PreparedQuery(qs, names, keep_resolved=True)
+    gold = O.Query(qs, names, keep_resolved=True)
+    assert dev.names == gold.names and dev.ntax < len(qs)

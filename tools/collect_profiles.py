@@ -20,7 +20,9 @@ def main():
                      ("sweep_q64.json", "r01_sweep_q64_1Mrefs.json"), ("stats/c2_kernel_stats.csv", "r01_bench_c2_kernel_stats_final.csv"),
                      ("pmc_fetch/f_counter_collection.csv", "r01_pmc_fetch_counter_collection.csv"), ("pmc_write/w_counter_collection.csv", "r01_pmc_write_counter_collection.csv"),
                      ("pmc_fetch_q4/f_counter_collection.csv", "r01_pmc_fetch_q4_counter_collection.csv"),
-                     ("pmc_sqa/a_counter_collection.csv", "r01_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r01_pmc_sq_b_counter_collection.csv")):
+                     ("pmc_sqa/a_counter_collection.csv", "r01_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r01_pmc_sq_b_counter_collection.csv"),
+                     ("hbm_read.txt", "r01_hbm_read_ceiling.txt"), ("emu_2.json", "r01_emulated_query_shard_of_2.json"), ("emu_4.json", "r01_emulated_query_shard_of_4.json"),
+                     ("emu_8.json", "r01_emulated_query_shard_of_8.json")):
         if os.path.exists(os.path.join(M, src)):
             shutil.copyfile(os.path.join(M, src), os.path.join(P, dst))
     summ = json.load(open(os.path.join(M, "pmc_summary.json")))

@@ -44,6 +44,8 @@ void del_query_structure (query_t qu);
 void create_query_indices (query_t qu);
 void reorder_query_structure (query_t qu);
 void exclude_redundant_query_sequences (query_t qu, int keep_more_resolved);
+/* same walk with the O(Q^2) pair test handed in (NULL: computed here); not in the reference's header */
+void exclude_redundant_query_sequences_given (query_t qu, int keep_more_resolved, const unsigned char *agree);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,42 @@
 /* prepare.c -- see prepare.h. */
 #include "prepare.h"
+#include "gpu_glue.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* exclude_redundant_query_sequences (src/fastaseq.c:797-841) with its O(Q^2) pair test on the device: the engine is opened on
+ * the still unpruned query set, the queries go through it as if they were references (uvaia_gpu_agree_on_polymorphic), and the
+ * order-dependent walk over the pairs runs here on the finished matrix.  Same survivors as the host-only function. */
+static void
+exclude_redundant_query_sequences_device (query_t query, int keep_resolved)
+{
+  const int n = query->aln->ntax;
+  const size_t batch = n < 2048 ? (size_t) n : 2048;
+  uvaia_gpu_ctx *gpu = NULL;
+  if (uvaia_gpu_open_query (&gpu, query, 1, -1, batch))
+    biomcmc_error ("pruning redundant queries on the GPU: %s (UVAIA_PRUNE=host runs the serial host loop instead)", uvaia_gpu_last_error (NULL));
+  unsigned char *agree = (unsigned char *) biomcmc_malloc ((size_t) n * n);
+  for (int a = 0; a < n; a += (int) batch) {
+    const int m = n - a < (int) batch ? n - a : (int) batch;
+    if (uvaia_gpu_agree_on_polymorphic (gpu, (const char *const *) query->aln->character->string + a, m, agree + (size_t) a * n))
+      biomcmc_error ("pruning redundant queries on the GPU: %s", uvaia_gpu_last_error (gpu));
+  }
+  uvaia_gpu_close (gpu);
+  exclude_redundant_query_sequences_given (query, keep_resolved, agree);
+  free (agree);
+}
+
+/* the pair test costs O(Q^2 x polymorphic columns) on one host thread (14 s at 3 000 queries): from this many queries on it
+   runs on the device.  UVAIA_PRUNE=host|device overrides. */
+#define UVAIA_PRUNE_DEVICE_FROM 512
+static int
+prune_on_device (int ntax)
+{
+  const char *e = getenv ("UVAIA_PRUNE");
+  if (e && !strcmp (e, "host")) return 0;
+  if (e && !strcmp (e, "device")) return 1;
+  return ntax >= UVAIA_PRUNE_DEVICE_FROM;
+}
 
 query_t
 uvaia_prepare_query (alignment aln, int trim, int dist, int acgt, double ambig_q, int keep_resolved, int is_ball)
@@ -12,7 +49,8 @@ uvaia_prepare_query (alignment aln, int trim, int dist, int acgt, double ambig_q
   create_query_indices (query);
   reorder_query_structure (query);
   if (is_ball || keep_resolved) {
-    exclude_redundant_query_sequences (query, keep_resolved);
+    if (prune_on_device (query->aln->ntax)) exclude_redundant_query_sequences_device (query, keep_resolved);
+    else exclude_redundant_query_sequences (query, keep_resolved);
     create_query_indices (query);
   }
   return query;

@@ -236,13 +236,22 @@ resolution_order (const query_t qu, const char *a, const char *b, const size_t *
 void
 exclude_redundant_query_sequences (query_t qu, int keep_more_resolved)
 {
+  exclude_redundant_query_sequences_given (qu, keep_more_resolved, NULL);
+}
+
+/* agree (nullable): ntax x ntax bytes, agree[j * ntax + i] != 0 when sequences i and j differ at no polymorphic column where
+   both are usable -- the pair test of the loop below, computed elsewhere (uvaia_gpu_agree_on_polymorphic) */
+void
+exclude_redundant_query_sequences_given (query_t qu, int keep_more_resolved, const unsigned char *agree)
+{
   if (!qu->consensus) biomcmc_error ("I can only exclude sequences after indices are created");
   const int n = qu->aln->ntax;
   char **s = qu->aln->character->string;
   int *alive = (int *) biomcmc_malloc ((size_t) (n > 0 ? n : 1) * sizeof (int)), n_alive = 0;
   for (int i = 0; i < n; i++) alive[i] = 1;
   for (int i = 0; i < n - 1; i++) for (int j = i + 1; j < n; j++) {
-    if (!alive[i] || !alive[j] || queries_conflict (qu, s[i], s[j])) continue;
+    if (!alive[i] || !alive[j]) continue;
+    if (agree ? !agree[(size_t) j * n + i] : queries_conflict (qu, s[i], s[j])) continue;
     int on_poly = resolution_order (qu, s[i], s[j], qu->idx, qu->n_idx);
     if (on_poly > 1) continue;
     int on_const = resolution_order (qu, s[i], s[j], qu->idx_m, qu->n_idx_m);

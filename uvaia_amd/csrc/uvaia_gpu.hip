@@ -857,6 +857,34 @@ int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
   return 0;
 }
 
+int uvaia_gpu_agree_on_polymorphic(uvaia_gpu_ctx *c, const char *const *seq, int n_seq, uint8_t *out)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (n_seq < 0 || (n_seq > 0 && (!seq || !out))) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
+  if ((size_t)n_seq > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_seq, c->max_pool);
+  if (n_seq == 0) return 0;
+  int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_seq, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
+  if (rc) return rc;
+  const int n_tiles = (n_seq + 63) / 64, ppad = n_tiles * 64;
+  rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
+  const bool prof = c->profile; c->profile = false;     // not the nearest-neighbour scan the statistics describe
+  rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
+  c->profile = prof;
+  if (rc) return rc;
+  uint8_t *d_out = nullptr;
+  const size_t bytes = (size_t)n_seq * c->nq;
+  HIPCHK(c, hipMalloc(&d_out, bytes));
+  dim3 grid((n_seq + 255) / 256, c->nq);
+  if (c->acgt) hipLaunchKernelGGL((agree_kernel<true>), grid, dim3(256), 0, c->stream, c->d_cnt, ppad, c->nq, n_seq, d_out);
+  else         hipLaunchKernelGGL((agree_kernel<false>), grid, dim3(256), 0, c->stream, c->d_cnt, ppad, c->nq, n_seq, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(c, UVAIA_GPU_EHIP, "agree_on_polymorphic: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, int n_ref, int64_t ordinal0, uint8_t *entered)
 {
   if (!c) return UVAIA_GPU_EINVAL;

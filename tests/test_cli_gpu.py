@@ -80,6 +80,29 @@ def test_uvaia_cli_matches_oracle(files, extra, kw):
     assert dump_seqs == [rseqs[i] for i in gold.saved]
 
 
+@pytest.mark.parametrize("acgt,trim,pool", [(False, 0, 64), (True, 230, 9185), (False, 230, 9185), (True, 0, 64)])
+def test_uvaia_cli_on_the_whole_bundled_database_matches_the_committed_table(tmp_path, acgt, trim, pool):
+    """BASELINE config[0]: `uvaia` on the reference's bundled alignment (9 185 sequences, xz) with the first 10 sample names as
+    queries, --nbest 5: the table must equal tests/golden/config1_oracle_snapshot.json row for row (no oracle in this test)."""
+    import json
+    snap = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_oracle_snapshot.json")))
+    run = [r for r in snap["runs"] if (r["acgt"], r["trim"], r["pool"]) == (acgt, trim, pool)][0]
+    names, seqs = F.load_bundled()
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:10]
+    _write_fasta(tmp_path / "query.fa", qn, [by[n] for n in qn])
+    out = str(tmp_path / "out")
+    cmd = [UVAIA, "-r", os.path.join(ROOT, "tests", "golden", "03.unique_acgt.aln.xz"), str(tmp_path / "query.fa"),
+           "-p", str(pool), "-n", "5", "--trim", str(trim), "-o", out] + (["--acgt"] if acgt else [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    rows = list(csv.reader(io.StringIO(_read_xz_text(out + ".csv.xz"))))[1:]
+    want = [[qname, r[0], str(rank)] + [str(v) for v in r[1:]]
+            for qname, qrows in zip(run["queries"], run["rows"]) for rank, r in enumerate(qrows, 1)]
+    assert rows == want
+    dump_names, _ = F.read_fasta_bytes(lzma.open(out + ".aln.xz", "rb").read())
+    assert len(dump_names) == run["n_saved"]
+
+
 @pytest.mark.parametrize("acgt", [False, True])
 @pytest.mark.parametrize("dist", [0, 1, 5])
 def test_ball_api_matches_oracle(bundled_db, acgt, dist):

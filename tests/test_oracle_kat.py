@@ -6,6 +6,7 @@ KAT 1: /root/reference/README.md:227-233 -- query England/NORW-3078E97/2021 agai
        column 8 depends on the whole (undocumented) query set of that run and is not a KAT.
 KAT 2: /root/reference/README.md:307-316 -- three toy sequences.
 """
+import fixtures as F
 import oracle_lib as O
 
 README_QUERY = "England/NORW-3078E97/2021"
@@ -54,3 +55,22 @@ def test_truncation_stops_at_maxdist():
     assert O.score4(a, b, maxdist=3) == [0, 0, 0, 3]
     assert O.score_acgt(a, b, maxdist=4) == [4, 4]
     assert O.score_acgt(a, b) == [10, 10]
+
+
+def test_oracle_reproduces_the_committed_config1_table(bundled_db):
+    """tests/golden/config1_oracle_snapshot.json (tools/make_golden.py) pins the oracle's own output on the bundled alignment:
+    a change in oracle/uvaia_oracle.c that alters a score, an order or a tolerance shows up here, on the CPU."""
+    import json
+    import os
+    snap = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config1_oracle_snapshot.json")))
+    names, seqs = bundled_db
+    by = dict(zip(names, seqs))
+    qn = F.sample_names_1k()[:10]
+    for run in snap["runs"]:
+        if run["pool"] != 64 and run["trim"] != 230:
+            continue                                 # four of the eight runs keep this test within seconds
+        q = O.Query([by[n] for n in qn], qn, acgt=run["acgt"], trim=run["trim"])
+        g = O.search(q, seqs, names, pool=run["pool"], nbest=run["nbest"])
+        assert list(q.names) == run["queries"] and list(g.final_T) == run["final_T"]
+        assert (g.n_lowqual, len(g.saved)) == (run["n_lowqual"], run["n_saved"])
+        assert [[[name] + list(score) for _, name, score in rows] for rows in g.rows] == run["rows"]

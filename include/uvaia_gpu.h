@@ -190,7 +190,8 @@ int    uvaia_gpu_db_append_packed (uvaia_gpu_ctx *ctx, const void *planes, const
 
 /* bytes the pair scan reads per reference (the default scan reads planes derived from the packed record for this query set) */
 size_t uvaia_gpu_scan_bytes_per_ref (const uvaia_gpu_ctx *ctx);
-/* bytes per reference of the planes derived for the open query set (what uvaia_gpu_db_rederive and the appends write) */
+/* bytes per reference uvaia_gpu_db_rederive writes (the planes that depend on the query set; the appends also write the
+ * valid-site plane, which does not) */
 size_t uvaia_gpu_derived_bytes_per_ref (const uvaia_gpu_ctx *ctx);
 /* bytes per packed reference in HBM */
 size_t uvaia_gpu_packed_bytes_per_ref (const uvaia_gpu_ctx *ctx);

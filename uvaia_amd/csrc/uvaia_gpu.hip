@@ -362,7 +362,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
 }
 
 // planes derived for the open query set (column-compressed scan) for the whole tiles that hold slots slot0 .. slot0 + n_ref - 1
-int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipStream_t st = nullptr)
+int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipStream_t st = nullptr, bool v_in_place = false)
 {
   if (!st) st = c->stream;
   if (c->fullscan || n_ref <= 0) return 0;
@@ -373,8 +373,10 @@ int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipS
   const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
   const int nblk = (int)(t1 - t0 + 1);
   if (c->derive_fused && c->d_split) {
-    if (c->acgt) hipLaunchKernelGGL((derive_all_kernel<true>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
-    else         hipLaunchKernelGGL((derive_all_kernel<false>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly);
+#define DERIVE_ALL(A, V) hipLaunchKernelGGL((derive_all_kernel<A, V>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly)
+    if (c->acgt) { if (v_in_place) DERIVE_ALL(true, false); else DERIVE_ALL(true, true); }
+    else         { if (v_in_place) DERIVE_ALL(false, false); else DERIVE_ALL(false, true); }
+#undef DERIVE_ALL
   } else if (c->acgt) {
     hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
     if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
@@ -843,9 +845,9 @@ size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
 }
 
 size_t uvaia_gpu_derived_bytes_per_ref(const uvaia_gpu_ctx *c)
-{ // bytes per reference of the planes built for the open query set (E, V, group counts, gathered columns, total)
+{ // bytes per reference uvaia_gpu_db_rederive writes for the open query set (E, group counts, gathered columns, total)
   if (!c || c->fullscan) return 0;
-  return (size_t)c->W4 * 32 + (size_t)c->W4 * 4 + (size_t)(c->NP4 + c->NR4) * 48 + 4;
+  return (size_t)c->W4 * 16 + (size_t)c->W4 * 4 + (size_t)(c->NP4 + c->NR4) * 48 + 4;   // E, grp, gathered planes, total; V is written once by the appends
 }
 
 int uvaia_gpu_set_query_tile(uvaia_gpu_ctx *c, int qt)
@@ -1106,7 +1108,7 @@ int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
       HIPCHK(c, hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
       c->derive_chunks.push_back(d);
     }
-    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), c->derive_stream); if (rc) return rc;
+    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), c->derive_stream, c->derive_fused && getenv("UVAIA_GPU_DERIVE_REWRITE_V") == nullptr); if (rc) return rc;
     c->derive_chunks[k].t0 = t0; c->derive_chunks[k].t1 = t1;
     HIPCHK(c, hipEventRecord(c->derive_chunks[k].done, c->derive_stream));
     k++;

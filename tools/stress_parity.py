@@ -25,7 +25,8 @@ def one(rng, k):
     nbest = rng.choice([1, 2, 5, 13, 40])
     pool = rng.choice([64, 97, 333, 1000, nref])
     env = {"UVAIA_GPU_RARE_MAX": rng.choice([None, "0", "1", "3", "50"]), "UVAIA_GPU_SCAN_QBLOCK": rng.choice([None, "0", "1"]),
-           "UVAIA_GPU_SUBSLICE": rng.choice([None, "64", "256"]), "UVAIA_GPU_SUBSLICE_MINQ": rng.choice([None, "1"])}
+           "UVAIA_GPU_SUBSLICE": rng.choice([None, "64", "256"]), "UVAIA_GPU_SUBSLICE_MINQ": rng.choice([None, "1"]),
+           "UVAIA_GPU_DERIVE_SPLIT": rng.choice([None, None, None, "1"])}
     for key, v in env.items():
         if v is None:
             os.environ.pop(key, None)
@@ -56,6 +57,11 @@ def one(rng, k):
         e2 = eng.search_resident(pool)
         n, T, sc, od = eng.drain()
         ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e2)[0]) == list(gold.saved)
+        eng.reset()                                                              # planes rebuilt in place, searched again
+        eng.db_rederive()
+        e3 = eng.search_resident(pool)
+        n, T, sc, od = eng.drain()
+        ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e3)[0]) == list(gold.saved)
     desc["cons"] = len(q.idx_c) > 0
     return desc, bool(ok)
 

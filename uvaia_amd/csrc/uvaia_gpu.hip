@@ -1064,6 +1064,10 @@ static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first
   // complete query columns (n_idx_c == 0) they have no effect at all and the slices are laid over the whole range.
   if (c->n_idx_c == 0) pool = std::max<size_t>(n, 1);
   size_t sub = c->subslice;
+  // With at most half the benchmark's query tiles (query shards, smaller query sets) the rebuild of the derived planes weighs
+  // more against the scan: slices of half the waves let the first scan start earlier and hide more of it (measured with the
+  // rebuild inside the step: 6.18 -> 6.03, 7.24 -> 7.10, 9.89 -> 9.26 ms for rank 0 of 2, 4, 8 query shards; 63 tiles: worse).
+  if (nqt <= 32) sub /= 2;
   if (nqt < 63) sub = std::min(pool, (sub * 63 / (size_t)std::max(nqt, 1) + 63) / 64 * 64);
   if (nq_act < c->subslice_minq && (c->n_idx_c > 0 || nqt < 4)) sub = pool;
   for (size_t a = first; a < first + n; a += pool) {

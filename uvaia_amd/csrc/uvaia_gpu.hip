@@ -272,7 +272,10 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
-    const int qblock = c->scan_qblock >= 0 ? c->scan_qblock : (nqt3 == 3 || nqt3 == 4 ? 1 : 0);      // measured: helps with one block of query tiles per reference tile (33..64 queries), not beyond
+    // lockstep blocks (4 query tiles x 1 reference tile, 2.4x less traffic): measured faster for 3..16 query tiles once the rebuild of
+    // the derived planes shares the memory system with the scan (rank 0 of 8 / 4 query shards: 9.26 -> 8.73, 7.16 -> 7.02 ms per step),
+    // even at 32 tiles, slower at 63 (4.86 -> 5.66 ms)
+    const int qblock = c->scan_qblock >= 0 ? c->scan_qblock : (nqt3 >= 3 && nqt3 <= 16 ? 1 : 0);
     dim3 grid3(qblock ? scan_grid_size((nqt3 + 3) / 4, n_tiles) : scan_grid_size(nqt3, (n_tiles + 3) / 4));
 #define SCAN3_LAUNCH(A) hipLaunchKernelGGL((scan3_kernel<16, A>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first, qblock)
     if (c->acgt) SCAN3_LAUNCH(true); else SCAN3_LAUNCH(false);

@@ -60,6 +60,25 @@ def test_query_preparation_with_redundancy(acgt, keep, ball):
         assert a.ntax < len(qs)
 
 
+def test_host_pruning_loop_stays_available_for_large_sets(monkeypatch):
+    """From 512 queries on the pair test of the pruning runs on the device (tests/test_query_prep_gpu.py); UVAIA_PRUNE=host keeps
+    the serial host loop, which is what this CPU test can run: same survivors as the oracle."""
+    monkeypatch.setenv("UVAIA_PRUNE", "host")
+    base, root, cols = F.synth_alignment(270, 400, seed=33, p_snp=0.01)
+    qs = []
+    for i, s in enumerate(base):
+        qs.append(s)
+        t = bytearray(s)
+        t[(i * 7) % 300:(i * 7) % 300 + 20] = b"N" * 20
+        qs.append(bytes(t))
+    names = ["q%d" % i for i in range(len(qs))]
+    assert len(qs) >= 512
+    a = H.PreparedQuery(qs, names, keep_resolved=True)
+    b = O.Query(qs, names, keep_resolved=True)
+    _same_query(a, b)
+    assert a.ntax < len(qs)
+
+
 def test_low_quality_queries_are_dropped():
     good, _, _ = F.synth_alignment(3, 600, seed=1)
     bad = b"N" * 400 + good[0][400:]

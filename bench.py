@@ -184,16 +184,14 @@ def main():
     launches = max(1, scan_launches)
     avg_ms = scan_ms / launches
     W = (args.nchar + 31) // 32
-    fullscan = os.environ.get("UVAIA_GPU_FULLSCAN", "0") not in ("", "0")
+    variant = eng.scan_variant()        # 2 column-compressed, 0 / 1 two counters over the packed planes, -1 four counters
+    fullscan = variant == -1
     ops_per_pair_word = (15 if args.mode == "iupac" else 8) if fullscan else 6
     valu_ops = float(local_refs) * (q1 - q0) * W * ops_per_pair_word * args.steps    # lane-ops in the timed region (this rank)
     valu_rate = valu_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     # The column-compressed scan does not read the 4-bit records themselves but planes derived from them for this query set
     # (E and V planes + the gathered polymorphic columns): fewer bytes per reference than the packed record.
-    if fullscan or os.environ.get("UVAIA_GPU_SCAN", "") in ("sgpr", "lds"):
-        kernel_bytes_per_ref = bytes_per_ref
-    else:
-        kernel_bytes_per_ref = eng.scan_bytes_per_ref()
+    kernel_bytes_per_ref = bytes_per_ref if variant != 2 else eng.scan_bytes_per_ref()
     # `achieved` is SURVEY 8d's implementation-independent figure: ceil(L*b/8) bytes per reference (14 952 at 4 bits, 11 214 with
     # 2 bits + validity plane), each reference byte once per launch.  The bytes THIS kernel has to read (derived planes, only the
     # word groups some query tile needs) are fewer; the rate on those is given next to it and is the one PMC FETCH_SIZE verifies.
@@ -206,7 +204,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
         "algorithmic_bytes_per_ref": survey_bytes_per_ref, "kernel_bytes_per_ref": kernel_bytes_per_ref,
         "achieved_on_kernel_bytes": round(on_kernel_bytes, 2), "frac_on_kernel_bytes": round(on_kernel_bytes / HBM_PEAK_GBS, 5),
-        "kernel": ("scan_%s_kernel" % args.mode) if fullscan else {"lds": "scan2v_kernel", "sgpr": "scan2_%s_kernel" % args.mode}.get(os.environ.get("UVAIA_GPU_SCAN", ""), "scan3_kernel"),
+        "kernel": {-1: "scan_%s_kernel" % args.mode, 0: "scan2_%s_kernel" % args.mode, 1: "scan2v_kernel"}.get(variant, "scan3_kernel"),
         "dense_equivalent_ops_per_pair_word": ops_per_pair_word,
         "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
         "algorithmic_bytes_per_launch": refs_per_launch * survey_bytes_per_ref,
@@ -304,7 +302,7 @@ def main():
                        "query_prepare_s": round(t_q1 - t_q0, 2), "engine_open_s": round(t_q2 - t_q1, 2)},
             "step_parts": {"includes_derived_planes": not args.search_only, "derived_planes_ms": round(derive_ms, 3), "scan_and_replay_ms": round(search_only_ms, 3),
                            "derived_planes_kernel": {"kernel": "derive_all_kernel", "bound": "hbm", "read_bytes_per_ref": bytes_per_ref, "written_bytes_per_ref": eng.derived_bytes_per_ref(),
-                                                     "achieved": round(local_refs * (bytes_per_ref + eng.derived_bytes_per_ref()) / (derive_ms * 1e-3) / 1e9, 1) if derive_ms > 0 else None,
+                                                     "achieved": round(local_refs * (bytes_per_ref + eng.derived_bytes_per_ref()) / (derive_ms * 1e-3) / 1e9, 1) if (derive_ms > 0 and eng.derived_bytes_per_ref()) else None,
                                                      "peak": HBM_PEAK_GBS, "unit": "GB/s (reads + writes, host-timed over its launches)"},
                            "note": "a step = planes derived from the resident packed records for this query set (uvaia_gpu_db_rederive) + pair scan + ordered replay; "
                                    "the two parts timed on their own after the timed region"},

@@ -190,6 +190,10 @@ int    uvaia_gpu_db_append_packed (uvaia_gpu_ctx *ctx, const void *planes, const
 
 /* bytes the pair scan reads per reference (the default scan reads planes derived from the packed record for this query set) */
 size_t uvaia_gpu_scan_bytes_per_ref (const uvaia_gpu_ctx *ctx);
+/* the pair scan of this context: 2 = column-compressed scan over planes derived for the query set (default above 16 queries),
+ * 0 = two-counter scan straight over the packed planes (default up to 16 queries: nothing is derived), 1 = its LDS-broadcast
+ * variant, -1 = four-counter scan (alignments above 49 000 columns) */
+int uvaia_gpu_scan_variant (const uvaia_gpu_ctx *ctx);
 /* bytes per reference uvaia_gpu_db_rederive writes (the planes that depend on the query set; the appends also write the
  * valid-site plane, which does not) */
 size_t uvaia_gpu_derived_bytes_per_ref (const uvaia_gpu_ctx *ctx);

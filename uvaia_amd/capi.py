@@ -18,7 +18,7 @@ SYMBOLS = [
     "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
-    "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_derived_bytes_per_ref", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
+    "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_derived_bytes_per_ref", "uvaia_gpu_scan_variant", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
     "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear", "uvaia_gpu_db_rederive",
     "uvaia_gpu_set_active_queries", "uvaia_gpu_max_tolerance", "uvaia_gpu_search_resident_pool",
 ]
@@ -101,6 +101,7 @@ def load_library():
         "uvaia_gpu_slice_buffers": (C.c_int, []),
         "uvaia_gpu_scan_bytes_per_ref": (C.c_size_t, [vp]),
         "uvaia_gpu_derived_bytes_per_ref": (C.c_size_t, [vp]),
+        "uvaia_gpu_scan_variant": (C.c_int, [vp]),
         "uvaia_gpu_set_query_tile": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_packed_bytes_per_ref": (C.c_size_t, [vp]),
         "uvaia_gpu_set_active_queries": (C.c_int, [vp, C.c_int, C.c_int]),
@@ -332,6 +333,9 @@ class Engine:
 
     def derived_bytes_per_ref(self):
         return self.L.uvaia_gpu_derived_bytes_per_ref(self.ctx)
+
+    def scan_variant(self):
+        return self.L.uvaia_gpu_scan_variant(self.ctx)
 
     def packed_bytes_per_ref(self):
         return self.L.uvaia_gpu_packed_bytes_per_ref(self.ctx)

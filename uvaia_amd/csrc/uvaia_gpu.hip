@@ -294,7 +294,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     return 0;
   }
-#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0)
+#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi)
   if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan2_acgt_kernel, 8); break; case 32: LAUNCH(scan2_acgt_kernel, 32); break; default: LAUNCH(scan2_acgt_kernel, 16); } }
   else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
 #undef LAUNCH
@@ -352,7 +352,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0]);
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
-                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, c->scan_variant == 2 ? c->d_tmin[0] : (const int2 *)nullptr, \
+                                    c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[0] : (const int2 *)nullptr, \
                                     c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
@@ -368,7 +368,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
 int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipStream_t st = nullptr, bool v_in_place = false)
 {
   if (!st) st = c->stream;
-  if (c->fullscan || n_ref <= 0) return 0;
+  if (c->fullscan || c->scan_variant != 2 || n_ref <= 0) return 0;     // only the column-compressed scan reads derived planes
   const bool is_db = (tiles == c->d_db);
   uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
   int *tote = is_db ? c->d_db_tote : c->d_batch_tote;
@@ -487,6 +487,9 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
   const char *env_scan = getenv("UVAIA_GPU_SCAN");
   if (env_scan) c->scan_variant = (strcmp(env_scan, "lds") == 0) ? 1 : (strcmp(env_scan, "sgpr") == 0) ? 0 : 2;
+  // One query tile: the column-compressed scan would move 25 KB per reference (building its planes) to read 1-8 KB; the
+  // two-counter scan over the packed planes reads each reference once (15 KB) and needs nothing derived.
+  else if (c->nq <= 16) c->scan_variant = 0;
   const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
   c->fullscan = env_full && atoi(env_full) != 0;
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
@@ -847,9 +850,15 @@ size_t uvaia_gpu_scan_bytes_per_ref(const uvaia_gpu_ctx *c)
                                                 : (size_t)(c->need_e_groups + c->need_v_groups) * 16 + (size_t)c->need_g_groups * 4 + (size_t)(c->NP4 + c->need_r_groups) * 16 * 3;
 }
 
+int uvaia_gpu_scan_variant(const uvaia_gpu_ctx *c)
+{ // which pair scan this context runs: 2 column-compressed (scan3_kernel), 0 two counters over the packed planes (scan2_*_kernel;
+  // default for at most 16 queries), 1 its LDS-broadcast form, -1 four counters (alignments above 49 000 columns)
+  return !c ? -2 : c->fullscan ? -1 : c->scan_variant;
+}
+
 size_t uvaia_gpu_derived_bytes_per_ref(const uvaia_gpu_ctx *c)
 { // bytes per reference uvaia_gpu_db_rederive writes for the open query set (E, group counts, gathered columns, total)
-  if (!c || c->fullscan) return 0;
+  if (!c || c->fullscan || c->scan_variant != 2) return 0;
   return (size_t)c->W4 * 16 + (size_t)c->W4 * 4 + (size_t)(c->NP4 + c->NR4) * 48 + 4;   // E, grp, gathered planes, total; V is written once by the appends
 }
 
@@ -1091,7 +1100,7 @@ int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
   // Issued on its own stream in the chunks the search will scan, one event each: the first slice's scan starts as soon as its
   // chunk is done and the rest is rebuilt next to it (the rebuild is bound by HBM, the scan by instruction issue).
   if (!c) return UVAIA_GPU_EINVAL;
-  if (!c->d_db || !c->db_n || c->fullscan) return 0;
+  if (!c->d_db || !c->db_n || c->fullscan || c->scan_variant != 2) return 0;
   HIPCHK(c, hipSetDevice(c->device));
   {   // searches still in flight read the planes: the rebuild queues behind them
     hipStream_t busy[4] = {c->stream, c->scan_streams[0], c->scan_streams[1], c->scan_streams[2]};
@@ -1357,7 +1366,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, c->scan_variant == 2 ? c->d_tmin[buf] : (const int2 *)nullptr, \
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
                                   c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }

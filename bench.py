@@ -209,8 +209,10 @@ def main():
         "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
         "algorithmic_bytes_per_launch": refs_per_launch * survey_bytes_per_ref,
         "dense_equivalent_tlaneops_per_s": round(valu_rate, 2),
-        "note": ("at %d resident queries every reference byte is reused by every query tile: the scan is bound by instruction issue "
-                 "(VALU popcounts + scalar bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (profiles/r01_sweep_q*.json, DESIGN.md 4.1)") % pq.ntax,
+        "note": (("%d resident queries = one query tile: the scan reads the packed planes of every reference exactly once "
+                  "(two-counter kernel, nothing derived); HBM is the bound (DESIGN.md 4.1)") % pq.ntax) if variant == 0 else
+                (("at %d resident queries every reference byte is reused by every query tile: the scan is bound by instruction issue "
+                  "(VALU popcounts + scalar bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (profiles/r01_sweep_q*.json, DESIGN.md 4.1)") % pq.ntax),
     }
 
     if achieved > HBM_PEAK_GBS:

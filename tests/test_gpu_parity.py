@@ -283,6 +283,29 @@ def test_separate_derive_kernels_agree_and_rederive_is_idempotent(acgt, monkeypa
     assert out[0][0] == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows] and out[0][1] == gold.final_T
 
 
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("nq", [5, 16])
+def test_small_query_sets_on_either_scan(monkeypatch, acgt, nq):
+    """Up to 16 queries the engine scans the packed planes directly (two-counter kernels with tile bounds); the column-compressed
+    scan can be forced and must give the same heaps.  Both against the oracle, streamed and resident."""
+    refs, root, cols = F.synth_alignment(900, 2100, seed=51)
+    qs, _, _ = F.synth_alignment(nq, 2100, seed=151, root=root, poly_cols=cols)
+    q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
+    with capi.Engine.from_query(q, nbest=4, max_pool=128) as eng:
+        assert eng.scan_variant() == 0
+    _assert_same_search(q, refs, 128, 4)
+    monkeypatch.setenv("UVAIA_GPU_SCAN", "compressed")
+    with capi.Engine.from_query(q, nbest=4, max_pool=128) as eng:
+        assert eng.scan_variant() == 2
+        eng.db_append(refs)
+        ent = eng.search_resident(128)
+        n, T, sc, od = eng.drain()
+    gold = O.search(q, refs, _names(len(refs)), pool=128, nbest=4, ambig_r=1.0)
+    assert capi.finalise_heaps(n, sc, od) == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows]
+    assert list(T) == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)
+    _assert_same_search(q, refs, 128, 4)
+
+
 def test_long_alignments_take_the_wide_counter_scan():
     """More than ~49 000 columns do not fit the 16-bit counter halves of the default scan: the engine switches to the
     four-counter scan by itself; results as the oracle's."""

@@ -26,7 +26,8 @@ def one(rng, k):
     pool = rng.choice([64, 97, 333, 1000, nref])
     env = {"UVAIA_GPU_RARE_MAX": rng.choice([None, "0", "1", "3", "50"]), "UVAIA_GPU_SCAN_QBLOCK": rng.choice([None, "0", "1"]),
            "UVAIA_GPU_SUBSLICE": rng.choice([None, "64", "256"]), "UVAIA_GPU_SUBSLICE_MINQ": rng.choice([None, "1"]),
-           "UVAIA_GPU_DERIVE_SPLIT": rng.choice([None, None, None, "1"])}
+           "UVAIA_GPU_DERIVE_SPLIT": rng.choice([None, None, None, "1"]),
+           "UVAIA_GPU_SCAN": rng.choice([None, None, "compressed"])}          # <= 16 queries scan the packed planes unless forced
     for key, v in env.items():
         if v is None:
             os.environ.pop(key, None)

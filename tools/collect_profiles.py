@@ -39,7 +39,10 @@ def main():
     # full-size launches only (a step may end with a shorter slice): use the maximum per dispatch
     fetch_kb, write_kb = scan_f["FETCH_SIZE"]["max"], scan_w["WRITE_SIZE"]["max"]
     q4_kb = pick("q4_1Mrefs_fetch", "scan3_kernel")["FETCH_SIZE"]["mean"]
-    q4_alg = q4["roofline"]["kernel_bytes_per_ref"] * q4["config"]["refs_per_gpu"]
+    # the PMC pass on 4 queries measures the column-compressed scan (forced: 4 queries get the packed-plane scan by default), whose
+    # bytes per reference at 4 queries are 4 148 (uvaia_gpu_scan_bytes_per_ref); the sweep file may describe the other kernel
+    q4_bpr = q4["roofline"]["kernel_bytes_per_ref"] if q4["roofline"]["kernel"] == "scan3_kernel" else 4148
+    q4_alg = q4_bpr * q4["config"]["refs_per_gpu"]
     out = {
         "note": "rocprofv3 --pmc, one counter group per pass (tools/measure_round.sh). FETCH_SIZE/WRITE_SIZE are KB per dispatch; gfx950 FETCH_SIZE "
                 "reports half of wide coalesced reads (MI355X_MICROARCH.md), hence x2. Check on the one-launch Q=4 run below: corrected fetch / bytes the kernel "
@@ -51,7 +54,7 @@ def main():
             "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
             "kernel_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] * bench["roofline"]["kernel_bytes_per_ref"] / bench["roofline"]["algorithmic_bytes_per_ref"],
         },
-        "q4_1Mrefs_one_launch_check": {"fetch_bytes_corrected": q4_kb * 1024 * 2, "kernel_bytes": q4_alg, "ratio": q4_kb * 1024 * 2 / q4_alg},
+        "q4_1Mrefs_one_launch_check": {"kernel": "scan3_kernel (UVAIA_GPU_SCAN=compressed)", "fetch_bytes_corrected": q4_kb * 1024 * 2, "kernel_bytes": q4_alg, "ratio": q4_kb * 1024 * 2 / q4_alg},
         "raw": summ,
     }
     sqa, sqb = pick("config1_sq_a", "scan3_kernel"), pick("config1_sq_b", "scan3_kernel")

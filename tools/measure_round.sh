@@ -12,7 +12,7 @@ step bench config1;  timeout -k 10 400 python bench.py --steps 5 --warmup 1 > $O
 step kernel stats;   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o c2 --output-format csv -- python bench.py --steps 5 --warmup 1 --cpu-refs 0 > $O/stats.log 2>&1 || exit 1
 step pmc fetch;      timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_fetch.log 2>&1 || exit 1
 step pmc write;      timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_write.log 2>&1 || exit 1
-step pmc fetch q4;   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_q4 -o f --output-format csv -- python bench.py --queries 4 --refs 1000000 --pool 1000000 --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_fetch_q4.log 2>&1 || exit 1
+step pmc fetch q4;   UVAIA_GPU_SCAN=compressed timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_q4 -o f --output-format csv -- python bench.py --queries 4 --refs 1000000 --pool 1000000 --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_fetch_q4.log 2>&1 || exit 1
 step pmc sq a;       timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM -d $O/pmc_sqa -o a --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_sqa.log 2>&1 || exit 1
 step pmc sq b;       timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $O/pmc_sqb -o b --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-refs 0 > $O/pmc_sqb.log 2>&1 || exit 1
 step acgt config1;   timeout -k 10 300 python bench.py --mode acgt --steps 5 --warmup 1 --cpu-refs 512 > $O/bench_acgt_c2.json 2> $O/bench_acgt_c2.err || exit 1

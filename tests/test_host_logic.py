@@ -79,6 +79,31 @@ def test_host_pruning_loop_stays_available_for_large_sets(monkeypatch):
     assert a.ntax < len(qs)
 
 
+def test_site_counts_agree_with_the_character_classes_for_every_byte():
+    """quick_count_sequence_non_N / quick_count_sequence_acgt are written as vectorisable byte comparisons (they sit in the serial
+    read loop); they must count exactly what is_site_valid / is_site_acgt (src/utils.c:255-295) say, for all 256 byte values."""
+    L = H.load_library()
+    L.quick_count_sequence_non_N.restype = C.c_int
+    L.quick_count_sequence_non_N.argtypes = [C.c_char_p, C.c_size_t]
+    L.quick_count_sequence_acgt.restype = C.c_int
+    L.quick_count_sequence_acgt.argtypes = [C.c_char_p, C.c_size_t]
+    L.is_site_valid.restype = C.c_int
+    L.is_site_valid.argtypes = [C.c_char]
+    L.is_site_acgt.restype = C.c_int
+    L.is_site_acgt.argtypes = [C.c_char]
+    valid = [L.is_site_valid(bytes([b])) for b in range(256)]
+    acgt = [L.is_site_acgt(bytes([b])) for b in range(256)]
+    assert sum(acgt) == 8 and 256 - sum(valid) == 9
+    for b in range(1, 256):                                  # single characters (0 would end the C string view, counted below)
+        one = bytes([b])
+        assert L.quick_count_sequence_non_N(one, 1) == valid[b] and L.quick_count_sequence_acgt(one, 1) == acgt[b], b
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 15, 16, 17, 63, 1000, 29903):
+        buf = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert L.quick_count_sequence_non_N(buf, n) == sum(valid[b] for b in buf)
+        assert L.quick_count_sequence_acgt(buf, n) == sum(acgt[b] for b in buf)
+
+
 def test_low_quality_queries_are_dropped():
     good, _, _ = F.synth_alignment(3, 600, seed=1)
     bad = b"N" * 400 + good[0][400:]

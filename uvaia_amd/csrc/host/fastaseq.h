@@ -37,6 +37,7 @@ int readfasta_next (readfasta_t rfas);
 void del_readfasta (readfasta_t rfas);
 
 int quick_count_sequence_non_N (char *s, size_t nsites);   /* valid sites over the given span */
+int quick_count_sequence_acgt (char *s, size_t nsites);    /* ACGT sites (src/fastaseq.c:650-656; not in the reference's header) */
 
 query_t new_query_structure_from_fasta (char *filename, int trim, int dist, int acgt);
 query_t new_query_structure_from_alignment (alignment aln, int trim, int dist, int acgt);   /* takes ownership of aln */

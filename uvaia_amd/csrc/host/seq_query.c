@@ -143,8 +143,22 @@ del_query_structure (query_t qu)
   free (qu);
 }
 
+/* character classes of src/utils.c:255-295 as comparisons (0xDF folds the letter case), for the loops below that visit every
+   character of every query; same sets as is_site_valid / is_site_acgt (tests/test_host_logic.py pins both for all 256 bytes) */
 static inline int
-usable (const query_t qu, char c) { return qu->acgt ? is_site_acgt (c) : is_site_valid (c); }
+char_is_valid (unsigned char c)
+{
+  const unsigned char up = c & 0xDF;
+  return !((up == 'N') | (up == 'X') | (up == 'O') | (c == '-') | (c == '?') | (c == '.'));
+}
+static inline int
+char_is_acgt (unsigned char c)
+{
+  const unsigned char up = c & 0xDF;
+  return (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+}
+static inline int
+usable (const query_t qu, char c) { return qu->acgt ? char_is_acgt ((unsigned char) c) : char_is_valid ((unsigned char) c); }
 
 void
 create_query_indices (query_t qu)
@@ -226,7 +240,7 @@ queries_conflict (const query_t qu, const char *a, const char *b)
 {
   for (int j = 0; j < qu->n_idx; j++) {
     char x = a[qu->idx[j]], y = b[qu->idx[j]];
-    if (qu->acgt ? is_site_acgt_distinct_pair (x, y) : (is_site_pair_valid (x, y) && x != y)) return 1;
+    if (x != y && usable (qu, x) && usable (qu, y)) return 1;
   }
   return 0;
 }

@@ -149,6 +149,25 @@ def test_host_heap_matches_oracle_heap():
             L.del_heap_t(h); OL.orc_heap_del(o)
 
 
+def test_readfasta_line_shapes(tmp_path):
+    """Clean upper-case lines take a copy-only path in the parser; CR LF endings, tabs, spaces, lower case and a last line without
+    a line end must come out exactly as the character-by-character path gives them."""
+    L = H.load_library()
+    body = (b">a\r\nACGTACGT\r\nNNNN--RY\r\n"            # CR LF, clean lines
+            b">b\nACGT\tAC gt\nacgtn\n"                      # tab, space, lower case
+            b">c\n" + b"ACGTNRYKM-" * 3000 + b"\n"            # one long clean line
+            b">d\nAC\nGT")                                     # no line end at the end of the file
+    p = tmp_path / "shapes.fa"
+    p.write_bytes(body)
+    want = [("a", b"ACGTACGTNNNN--RY"), ("b", b"ACGTACGTACGTN"), ("c", b"ACGTNRYKM-" * 3000), ("d", b"ACGT")]
+    r = L.new_readfasta(str(p).encode())
+    got = []
+    while L.readfasta_next(r) >= 0:
+        got.append((r.contents.name.decode(), C.string_at(r.contents.seq, r.contents.seqlength)))
+    L.del_readfasta(r)
+    assert got == want
+
+
 def test_readfasta_streams_plain_gz_xz(tmp_path):
     L = H.load_library()
     recs = [("seq one", b"acgtnn--ACGT"), ("s2", b"AC GT\nAC"), ("third/3", b"NNNN")]

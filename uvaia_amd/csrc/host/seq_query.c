@@ -37,7 +37,13 @@ append_sequence_line (readfasta_t r, const char *line, size_t len)
   }
   r->seq = (char *) biomcmc_realloc (r->seq, r->seqlength + len + 1);
   char *w = r->seq + r->seqlength;
-  for (size_t i = 0; i < len; i++) { const unsigned char m = map[(unsigned char) line[i]]; *w = (char) m; w += (m != 0); }
+  /* the usual line is upper case with nothing to drop except the line end: one vectorisable pass finds out, then a plain copy */
+  size_t body = len;
+  while (body > 0 && (line[body - 1] == '\n' || line[body - 1] == '\r')) body--;
+  size_t odd = 0;
+  for (size_t i = 0; i < body; i++) { const unsigned char c = (unsigned char) line[i]; odd += (size_t) ((c <= ' ') | ((unsigned char) (c - 'a') < 26)); }
+  if (!odd) { memcpy (w, line, body); w += body; }
+  else for (size_t i = 0; i < len; i++) { const unsigned char m = map[(unsigned char) line[i]]; *w = (char) m; w += (m != 0); }
   *w = '\0';
   const size_t added = (size_t) (w - (r->seq + r->seqlength));
   r->seqlength += added;

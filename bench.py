@@ -6,15 +6,20 @@ against the whole resident query set and passed through the ordered gate + top-k
 reference file, src/nearest.c:249-330 of the reference), heaps reset between steps.  Inputs are synthetic
 SARS-CoV-2-shaped alignments (uvaia_amd/csrc/host/synth.c, seed 20241008) and are resident in HBM before the timed region.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N rank processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N=1 runs BASELINE.json config[1]: 1 000 queries x 100 000 references x 29 903 columns, 4-bit IUPAC planes, top-k 100.
-With N>1 every rank holds its own 100 000-reference shard of the database (weak scaling, block-cyclic in stream order).
+N=1 runs BASELINE.json config[1]: 1 000 queries x 100 000 references x 29 903 columns, 4-bit IUPAC planes, top-k 100, and adds
+to the same JSON line a `sweep` of other resident-query counts (1, 4, 16 queries x 1 M references: the HBM-bound regime) and
+BASELINE config[2] (10 000 x 1 000 000, --acgt), each with its own roofline.  With N>1 every rank holds its own 100 000-reference
+shard of the database (weak scaling).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,10 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
-QUERY_INDEX0 = 1 << 40           # queries come from the same process, disjoint sequence numbers
+QUERY_INDEX0 = 1 << 40           # queries come from the same generator, disjoint sequence numbers
+KERNEL_SOURCES = ["uvaia_gpu.hip", "kernels_pack.inc", "kernels_scan_history.inc", "kernels_scan3.inc", "kernels_consensus.inc", "kernels_replay.inc"]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -41,10 +47,14 @@ def parse():
     ap.add_argument("--nchar", type=int, default=29903)
     ap.add_argument("--seed", type=int, default=20241008)
     ap.add_argument("--qt", type=int, default=0, help="query tile of the scan kernel (8/16/32, 0 = default)")
-    ap.add_argument("--cpu-refs", type=int, default=1536, help="references in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-refs-1thread", type=int, default=48, help="sample of the single-thread CPU baseline")
-    ap.add_argument("--multi", choices=["shards", "ring"], default="shards",
-                    help="N > 1: 'shards' = every GPU holds the whole database and a range of the queries (no data-path exchange); "
+    ap.add_argument("--cpu-refs", type=int, default=8192, help="references in the timed CPU-baseline sample (0 = skip), after --cpu-warm untimed ones")
+    ap.add_argument("--cpu-warm", type=int, default=2048, help="references fed to the CPU baseline before its timed sample (heaps full, tolerances settled)")
+    ap.add_argument("--cpu-refs-1thread", type=int, default=256, help="timed sample of the single-thread CPU baseline (same warm state)")
+    ap.add_argument("--parity-refs", type=int, default=1536, help="references of the in-run GPU-vs-oracle check")
+    ap.add_argument("--multi", choices=["shards", "ring", "refshard"], default="refshard",
+                    help="N > 1: 'refshard' = every GPU derives and scans 1/N of the references against all queries, the pair counters "
+                         "move by one RCCL all-to-all per slice, the ordered replay is sharded by query (uvaia_amd/refshard.py); "
+                         "'shards' = every GPU holds the whole database and a range of the queries (no data-path exchange); "
                          "'ring' = every GPU holds 1/N of the database, heap state handed rank to rank (uvaia_amd/ring.py)")
     ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N",
                     help="single process: do the work of rank 0 of N query shards (whole stream of N x --refs references, 1/N of the queries) "
@@ -53,23 +63,222 @@ def parse():
                     help="leave the per-query-set planes of the resident database as the load built them (the timed step then "
                          "holds scan + replay only); by default every step rebuilds them first")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
-    return ap.parse_args()
+    ap.add_argument("--no-sweep", action="store_true", help="headline workload only (profiling runs)")
+    ap.add_argument("--sweep-refs", type=int, default=1000000, help="references of the sweep entries")
+    return ap.parse_args(argv)
+
+
+def kernel_source_hash():
+    """sha256 over the engine's kernel sources: PMC figures in profiles/ are only quoted for the build they were measured on"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "uvaia_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start N rank processes (fresh children, before anything in this process touches the GPU),
+    pass their output through and exit with their code.  Never falls back to one rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
+
+
+def survey_bytes_per_ref(nchar, mode):
+    """SURVEY 8d's implementation-independent figure: ceil(L*b/8) bytes per reference (14 952 at 4 bits; 2 bits + validity plane: 11 214)"""
+    return (nchar * 4 + 7) // 8 if mode == "iupac" else (nchar * 2 + 7) // 8 + (nchar + 7) // 8
+
+
+def roofline_of(eng, scan_ms, scan_launches, refs_scanned, nchar, mode, n_query):
+    launches = max(1, scan_launches)
+    avg_ms = scan_ms / launches
+    variant = eng.scan_variant()        # 2 column-compressed, 0 / 1 two counters over the packed planes, -1 four counters
+    bytes_per_ref = eng.packed_bytes_per_ref()
+    kernel_bytes_per_ref = bytes_per_ref if variant != 2 else eng.scan_bytes_per_ref()
+    sb = survey_bytes_per_ref(nchar, mode)
+    refs_per_launch = float(refs_scanned) / launches
+    achieved = refs_per_launch * sb / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    on_kernel = refs_per_launch * kernel_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    r = {
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "algorithmic_bytes_per_ref": sb, "kernel_bytes_per_ref": kernel_bytes_per_ref,
+        "achieved_on_kernel_bytes": round(on_kernel, 2), "frac_on_kernel_bytes": round(on_kernel / HBM_PEAK_GBS, 5),
+        "kernel": {-1: "scan_%s_kernel" % mode, 0: "scan2_%s_kernel" % mode, 1: "scan2v_kernel"}.get(variant, "scan3_kernel"),
+        "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
+        "algorithmic_bytes_per_launch": refs_per_launch * sb,
+        "note": (("%d resident queries = one query tile: the scan reads the packed planes of every reference exactly once "
+                  "(nothing derived); HBM is the bound (DESIGN.md 4.1)") % n_query) if variant == 0 else
+                (("at %d resident queries every reference byte is reused by every query tile: the scan is bound by instruction issue "
+                  "(popcounts + item-stream bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (`sweep`, DESIGN.md 4.1)") % n_query),
+    }
+    if achieved > HBM_PEAK_GBS:
+        r["frac_note"] = ("the SURVEY figure counts the whole packed record of every reference; this kernel reads only the derived planes of the "
+                          "word groups some query needs (kernel_bytes_per_ref), so the nominal rate exceeds the peak: frac_on_kernel_bytes is the physical HBM fraction")
+    return r
+
+
+def attach_pmc_traffic(roofline, n_query, refs, pool, mode):
+    """HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process): quoted only
+    when those passes measured THIS build of the kernels (hash of the kernel sources) on this workload; otherwise `traffic` stays null."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+    except Exception:
+        return
+    if pm.get("kernel_source_hash") != kernel_source_hash():
+        roofline["traffic_note"] = "profiles/r02_pmc_traffic.json was measured on another build of the kernels: not quoted"
+        return
+    e = pm.get(roofline["kernel"])
+    if not e:
+        return
+    cfg = e.get("config", {})
+    if all(cfg.get(k) == v for k, v in (("queries", n_query), ("refs_per_gpu", refs), ("pool", pool), ("mode", mode))):
+        roofline["traffic"] = e["hbm_side_read_bytes_per_launch"] + e["write_bytes_per_launch"]
+        roofline["traffic_note"] = ("FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch, separate --pmc passes of this build "
+                                    "(profiles/r02_pmc_traffic.json, kernel source hash %s); L2 misses incl. Infinity-Cache hits" % pm["kernel_source_hash"])
+        if e.get("issue"):
+            roofline["issue"] = e["issue"]
+
+
+def single_gpu_workload(hostlib, n_query, refs, mode, nbest, pool, steps, warmup, nchar, seed, preset, device, qt=0, search_only=False):
+    """One resident-database workload on one GPU (no exchange): returns the figures of a sweep entry.  Also used by the headline."""
+    gen = hostlib.Synth(nchar, seed=seed, preset=preset)
+    qseqs, _ = gen.generate_bytes(QUERY_INDEX0, n_query)
+    qnames = ["query_%d" % i for i in range(n_query)]
+    t0 = time.time()
+    pq = hostlib.PreparedQuery(qseqs, qnames, acgt=(mode == "acgt"))
+    t1 = time.time()
+    pool = min(pool, refs)
+    eng = pq.open_engine(nbest=nbest, max_pool=pool, device=device)
+    t2 = time.time()
+    if qt:
+        eng.set_query_tile(qt)
+    eng.db_reserve(refs)
+    for a in range(0, refs, 8192):
+        n = min(8192, refs - a)
+        rows, non_n = gen.generate(a, n)
+        eng.db_append_block(rows, non_n)
+    load_s = time.time() - t2
+
+    def step(derive=not search_only):
+        eng.reset()
+        if derive:
+            eng.db_rederive()
+        eng.search_resident(pool, ordinal0=0, want_entered=False)
+        eng.sync()
+
+    step()
+    for _ in range(warmup):
+        step()
+    eng.scan_stats(reset=True)
+    import gc
+    gc.collect(); gc.disable()
+    t_a = time.perf_counter()
+    for _ in range(steps):
+        step()
+    elapsed = time.perf_counter() - t_a
+    gc.enable()
+    scan_ms, scan_launches, _ = eng.scan_stats(reset=True)
+    ms = 1e3 * elapsed / max(1, steps)
+    sb = survey_bytes_per_ref(nchar, mode)
+    out = {
+        "workload": "%d queries x %d refs x %d cols, %s, top-k %d, pool %d" % (pq.ntax, refs, nchar, "4-bit IUPAC planes" if mode == "iupac" else "2-bit + validity planes (--acgt)", nbest, pool),
+        "queries": pq.ntax, "refs": refs, "mode": mode, "steps": steps, "warmup": warmup,
+        "value": round(refs * steps / elapsed, 2), "unit": "ref-seqs/s", "ms_per_step": round(ms, 3),
+        "whole_step_GBps": round(refs * sb / (ms * 1e-3) / 1e9, 1), "whole_step_frac_of_hbm_peak": round(refs * sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": roofline_of(eng, scan_ms, scan_launches, refs * steps, nchar, mode, pq.ntax),
+        "db_load_s": round(load_s, 2), "query_prepare_s": round(t1 - t0, 2), "engine_open_s": round(t2 - t1, 2),
+    }
+    eng.close()
+    return out
+
+
+def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_timed, n_one):
+    """The oracle's restatement of the reference loops (src/nearest.c:249-330) on the host cores, with the heaps in the state a long
+    run spends its time in: `n_warm` references are fed untimed (heaps fill, tolerances settle: the early exits of
+    src/nearest.c:488-496 fire), then `n_timed` references are timed on all threads and `n_one` more on one thread."""
+    import ctypes as C
+    L = O.lib()
+    oq = O.Query(qseqs, qnames, acgt=(mode == "acgt"))
+    cores = L.orc_max_threads()
+    bpool = 512                                         # batches small enough that the timed feed does the work, as --pool 512 would
+    s = L.orc_search_new(oq.ptr, bpool, nbest, 0.5, 0)
+
+    def feed(a, n):
+        seqs, _ = gen.generate_bytes(first + a, n)
+        names = ["ref_%d" % (a + i) for i in range(n)]
+        t0 = time.perf_counter()
+        rc = L.orc_search_feed(s, n, O._cstr_array(seqs), O._cstr_array(names), None)
+        assert rc == 0
+        return time.perf_counter() - t0
+
+    try:
+        feed(0, n_warm)
+        t_all = feed(n_warm, n_timed)
+        out = {"value": round(n_timed / t_all, 2), "unit": "ref-seqs/s", "cores": cores, "kind": "port",
+               "sample": "%d references of the same database vs the same %d queries after %d untimed warm-up references (heaps full), "
+                         "batches of %d, OpenMP over %d threads, %.1f s" % (n_timed, oq.ntax, n_warm, bpool, cores, t_all)}
+        if n_one > 0:
+            L.orc_set_threads(1)
+            t_one = feed(n_warm + n_timed, n_one)
+            L.orc_set_threads(cores)
+            out["value_1_thread"] = round(n_one / t_one, 2)
+            out["sample_1_thread"] = "the next %d references, same warm state, 1 thread, %.1f s" % (n_one, t_one)
+    finally:
+        L.orc_search_del(s)
+    try:
+        out["host"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return out
+
+
+def parity_on_timed_path(O, capi, pq, gen, first, qseqs, qnames, mode, pool, nbest, n_s, device, qt):
+    """A sample of the benchmark database through the sequence of calls the timed step makes (resident database, rebuild of the
+    derived planes on its own stream, sub-sliced search) must give the oracle's heaps, tolerances and dump flags."""
+    sample, _ = gen.generate_bytes(first, n_s)
+    oq = O.Query(qseqs, qnames, acgt=(mode == "acgt"))
+    p = min(pool, n_s)
+    gold = O.search(oq, sample, ["ref_%d" % i for i in range(n_s)], pool=p, nbest=nbest, ambig_r=0.5)
+    with pq.open_engine(nbest=nbest, max_pool=p, device=device) as e2:
+        if qt:
+            e2.set_query_tile(qt)
+        e2.db_reserve(n_s)
+        rows, non_n = gen.generate(first, n_s)
+        e2.db_append_block(rows, non_n)
+        e2.reset()
+        e2.db_rederive()
+        ent = e2.search_resident(p)
+        e2.sync()
+        n, T, sc, od = e2.drain()
+    got = capi.finalise_heaps(n, sc, od)
+    return bool(list(T) == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)
+                and all(got[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(oq.ntax)))
 
 
 def main():
     args = parse()
-    import torch
-    from uvaia_amd import capi, hostlib
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args)                       # does not return
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: refusing to report a line for a different number of ranks" % (world, args.gpus))
+
+    import torch
+    from uvaia_amd import capi, hostlib
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # UVAIA_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (state blobs via host memory)
+    # UVAIA_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (exchanges via host memory)
     backend = os.environ.get("UVAIA_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -94,19 +303,31 @@ def main():
     pq = hostlib.PreparedQuery(qseqs, qnames, acgt=(args.mode == "acgt"))
     t_q1 = time.time()
     emu = args.emulate_shard_of if (world == 1 and args.emulate_shard_of > 1) else 0
-    shard_mode = (world > 1 and args.multi == "shards") or emu > 0
+    multi = args.multi if world > 1 else ("shards" if emu else None)
+    shard_mode = multi == "shards"
     local_refs = (emu or world) * args.refs if shard_mode else args.refs      # query shards: every rank holds (and scans) the whole stream
     pool = min(args.pool, local_refs)
+    from uvaia_amd import ring, shards
+    on_gpu = backend == "nccl"
+    plan = None
+    if multi == "refshard":
+        from uvaia_amd import refshard
+        plan = refshard.Plan(world, rank, args.refs, pq.ntax)
+        pool = plan.slice_refs
     eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank)
     t_q2 = time.time()
     if args.qt:
         eng.set_query_tile(args.qt)
     eng.db_reserve(local_refs)
     t0 = time.time()
-    from uvaia_amd import ring, shards
     # ring: block-cyclic shard, stripe s (= one pool of world*pool references of the stream) = slice s of rank 0, 1, ...
-    # shards: the whole stream on every rank
-    slices = [ring.Slice(0, local_refs, 0)] if shard_mode else ring.block_cyclic_layout(args.refs, pool, rank, world)
+    # shards: the whole stream on every rank;  refshard: slice s of the stream = rank-major pieces, see uvaia_amd/refshard.py
+    if multi == "refshard":
+        slices = plan.local_slices()
+    elif shard_mode or world == 1:
+        slices = [ring.Slice(0, local_refs, 0)]
+    else:
+        slices = ring.block_cyclic_layout(args.refs, pool, rank, world)
     first = slices[0].ordinal0
     chunk = 8192
     for sl in slices:
@@ -116,12 +337,12 @@ def main():
             eng.db_append_block(rows, non_n)
     load_s = time.time() - t0
     bytes_per_ref = eng.packed_bytes_per_ref()
-    on_gpu = backend == "nccl"
-    comm = ring.TorchRingComm(dist, rank, world, cuda=on_gpu) if (dist is not None and not shard_mode) else None
+    comm = ring.TorchRingComm(dist, rank, world, cuda=on_gpu) if (dist is not None and multi == "ring") else None
     nbytes = eng.state_bytes()
     cons = len(pq.idx_c) > 0
     q0, q1 = shards.query_shard(pq.ntax, rank, emu or world) if shard_mode else (0, pq.ntax)
     allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons and dist is not None) else None
+    xchg = refshard.TorchExchange(dist, plan, eng, "cuda" if on_gpu else "cpu") if multi == "refshard" else None
 
     # ---- timed region
     # One step = everything one search of the resident database costs for this query set: the planes derived from the packed
@@ -135,6 +356,8 @@ def main():
             eng.search_resident(pool, ordinal0=0, want_entered=False)
         elif shard_mode:   # no data-path exchange (one all-reduced int per pool if the query set has complete constant columns)
             shards.run_query_shard(eng, q0, q1, local_refs, pool, cons, allmax)
+        elif multi == "refshard":
+            refshard.run(eng, plan, xchg, cons)
         else:   # scans run concurrently on all ranks; the heap state visits the ranks in stream order, pipelined by query group
             ring.run_ring_grouped(eng, comm, rank, world, slices, pq.ntax, cons,
                                   lambda nb: ring.TorchStateBuffer(nb, "cuda" if on_gpu else "cpu"))
@@ -160,19 +383,21 @@ def main():
     scan_ms, scan_launches, scan_bytes = eng.scan_stats(reset=True)
     admitted, demanded, dense_rescans = eng.replay_stats(reset=True)
     # the two parts of a step on their own (untimed for `value`): derived planes only, scan + replay only
-    gc.disable()
-    t_d = time.perf_counter()
-    for _ in range(args.steps):
-        eng.db_rederive()
-        eng.sync()
-    derive_ms = 1e3 * (time.perf_counter() - t_d) / max(1, args.steps)
-    t_d = time.perf_counter()
-    for _ in range(args.steps):
-        step(derive=False)
-    search_only_ms = 1e3 * (time.perf_counter() - t_d) / max(1, args.steps)
-    gc.enable()
-    eng.scan_stats(reset=True)
-    eng.replay_stats(reset=True)
+    derive_ms = search_only_ms = 0.0
+    if world == 1:
+        gc.disable()
+        t_d = time.perf_counter()
+        for _ in range(args.steps):
+            eng.db_rederive()
+            eng.sync()
+        derive_ms = 1e3 * (time.perf_counter() - t_d) / max(1, args.steps)
+        t_d = time.perf_counter()
+        for _ in range(args.steps):
+            step(derive=False)
+        search_only_ms = 1e3 * (time.perf_counter() - t_d) / max(1, args.steps)
+        gc.enable()
+        eng.scan_stats(reset=True)
+        eng.replay_stats(reset=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,109 +405,35 @@ def main():
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = (emu or world) * args.refs * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (pair scan): algorithmic bytes per launch / mean launch time (HIP events)
-    launches = max(1, scan_launches)
-    avg_ms = scan_ms / launches
-    W = (args.nchar + 31) // 32
-    variant = eng.scan_variant()        # 2 column-compressed, 0 / 1 two counters over the packed planes, -1 four counters
-    fullscan = variant == -1
-    ops_per_pair_word = (15 if args.mode == "iupac" else 8) if fullscan else 6
-    valu_ops = float(local_refs) * (q1 - q0) * W * ops_per_pair_word * args.steps    # lane-ops in the timed region (this rank)
-    valu_rate = valu_ops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
-    # The column-compressed scan does not read the 4-bit records themselves but planes derived from them for this query set
-    # (E and V planes + the gathered polymorphic columns): fewer bytes per reference than the packed record.
-    kernel_bytes_per_ref = bytes_per_ref if variant != 2 else eng.scan_bytes_per_ref()
-    # `achieved` is SURVEY 8d's implementation-independent figure: ceil(L*b/8) bytes per reference (14 952 at 4 bits, 11 214 with
-    # 2 bits + validity plane), each reference byte once per launch.  The bytes THIS kernel has to read (derived planes, only the
-    # word groups some query tile needs) are fewer; the rate on those is given next to it and is the one PMC FETCH_SIZE verifies.
-    survey_bytes_per_ref = (args.nchar * 4 + 7) // 8 if args.mode == "iupac" else (args.nchar * 2 + 7) // 8 + (args.nchar + 7) // 8
-    refs_per_launch = float(local_refs) * args.steps / launches
-    achieved = refs_per_launch * survey_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    on_kernel_bytes = refs_per_launch * kernel_bytes_per_ref / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "algorithmic_bytes_per_ref": survey_bytes_per_ref, "kernel_bytes_per_ref": kernel_bytes_per_ref,
-        "achieved_on_kernel_bytes": round(on_kernel_bytes, 2), "frac_on_kernel_bytes": round(on_kernel_bytes / HBM_PEAK_GBS, 5),
-        "kernel": {-1: "scan_%s_kernel" % args.mode, 0: "scan2_%s_kernel" % args.mode, 1: "scan2v_kernel"}.get(variant, "scan3_kernel"),
-        "dense_equivalent_ops_per_pair_word": ops_per_pair_word,
-        "avg_launch_ms": round(avg_ms, 4), "launches": scan_launches,
-        "algorithmic_bytes_per_launch": refs_per_launch * survey_bytes_per_ref,
-        "dense_equivalent_tlaneops_per_s": round(valu_rate, 2),
-        "note": (("%d resident queries = one query tile: the scan reads the packed planes of every reference exactly once "
-                  "(two-counter kernel, nothing derived); HBM is the bound (DESIGN.md 4.1)") % pq.ntax) if variant == 0 else
-                (("at %d resident queries every reference byte is reused by every query tile: the scan is bound by instruction issue "
-                  "(VALU popcounts + scalar bookkeeping), not by HBM; the HBM-bound regime is Q <= 16 (profiles/r01_sweep_q*.json, DESIGN.md 4.1)") % pq.ntax),
-    }
+    # ---- roofline of the dominant kernel (pair scan): algorithmic bytes per launch / mean launch time (HIP events on its stream)
+    roofline = roofline_of(eng, scan_ms, scan_launches, float(local_refs) * args.steps, args.nchar, args.mode, pq.ntax)
+    if world == 1 and not emu:
+        attach_pmc_traffic(roofline, pq.ntax, args.refs, pool, args.mode)
+    derived_bytes = eng.derived_bytes_per_ref()
+    packed_bytes = bytes_per_ref
 
-    if achieved > HBM_PEAK_GBS:
-        roofline["frac_note"] = ("the SURVEY figure counts the whole packed record of every reference; with %d queries this kernel reads only the derived "
-                                 "planes of the word groups some query needs (kernel_bytes_per_ref), so the nominal rate exceeds the peak: "
-                                 "frac_on_kernel_bytes is the physical HBM fraction (PMC-verified, profiles/r01_pmc_traffic.json)") % pq.ntax
-    # HBM-side traffic of the scan from the committed PMC passes (rocprofv3 cannot run inside this process); only quoted
-    # when the run is the configuration those passes measured
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["scan3_kernel"]
-        same = all(pm["config"][k] == v for k, v in (("queries", pq.ntax), ("refs_per_gpu", args.refs), ("pool", pool), ("mode", args.mode)))
-        if same and not fullscan and world == 1 and os.environ.get("UVAIA_GPU_SCAN", "") == pm.get("variant", ""):
-            roofline["traffic"] = pm["hbm_side_read_bytes_per_launch"] + pm["write_bytes_per_launch"]
-            roofline["traffic_note"] = "FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch, profiles/r01_pmc_traffic.json; L2 misses incl. Infinity-Cache hits"
-            if pm.get("wave_instructions_all_dispatches") and pm.get("instruction_mix_all_dispatches", {}).get("SQ_WAVES"):
-                # instruction issue: wave-instructions per (16 queries x 64 references) wave from the committed SQ passes, times the
-                # waves of the timed region, over the measured scan time; peak = tools/issue_rate.hip (VALU + SALU mixed, whole chip)
-                per_wave = pm["wave_instructions_all_dispatches"] / pm["instruction_mix_all_dispatches"]["SQ_WAVES"]
-                waves = ((q1 - q0 + 15) // 16) * ((local_refs + 63) // 64) * args.steps
-                rate = per_wave * waves / (scan_ms * 1e-3) / 1e9
-                roofline["issue"] = {"wave_instructions_per_wave": round(per_wave), "achieved": round(rate, 1), "peak": 1037.0, "unit": "G wave-instr/s",
-                                     "frac": round(rate / 1037.0, 3), "source": "profiles/r01_pmc_traffic.json, profiles/r01_issue_rate_microbench.txt"}
-    except Exception:
-        pass
-
-    # ---- CPU baseline (rank 0, N=1 only): the oracle's restatement of the reference loops on a bounded sample
+    # ---- CPU baseline and the in-run parity check (rank 0, N=1 only)
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not emu and args.cpu_refs > 0:
+    if rank == 0 and world == 1 and not emu and (args.cpu_refs > 0 or not args.no_parity):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        n_s = min(args.cpu_refs, args.refs)
-        sample, _ = gen.generate_bytes(first, n_s)
-        snames = ["ref_%d" % i for i in range(n_s)]
-        oq = O.Query(qseqs, qnames, acgt=(args.mode == "acgt"))
-        cores = O.lib().orc_max_threads()
-        t0 = time.perf_counter()
-        gold = O.search(oq, sample, snames, pool=min(pool, n_s), nbest=args.nbest, ambig_r=0.5)
-        cpu_s = time.perf_counter() - t0
-        cpu = {"value": round(n_s / cpu_s, 2), "unit": "ref-seqs/s", "cores": cores, "kind": "port",
-               "sample": "first %d references of the same database vs the same %d queries, pool %d, OpenMP over %d threads, %.1f s"
-                         % (n_s, oq.ntax, min(pool, n_s), cores, cpu_s)}
-        try:        # the same restatement on one thread, on a smaller sample
-            import ctypes
-            gomp = ctypes.CDLL("libgomp.so.1")
-            n_1 = max(1, min(n_s, args.cpu_refs_1thread))
-            gomp.omp_set_num_threads(1)
-            t0 = time.perf_counter()
-            O.search(oq, sample[:n_1], snames[:n_1], pool=min(pool, n_1), nbest=args.nbest, ambig_r=0.5)
-            t1 = time.perf_counter() - t0
-            gomp.omp_set_num_threads(cores)
-            cpu["value_1_thread"] = round(n_1 / t1, 2)
-            cpu["sample_1_thread"] = "first %d references, 1 thread, %.1f s" % (n_1, t1)
-        except OSError:
-            pass
-        try:
-            cpu["host"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-        except Exception:
-            pass
-        if not args.no_parity:      # the same sample through the GPU engine must give the same heaps
-            eng.reset()
-            with pq.open_engine(nbest=args.nbest, max_pool=min(pool, n_s), device=local_rank) as e2:
-                if args.qt:
-                    e2.set_query_tile(args.qt)
-                e2.push(sample)
-                n, T, sc, od = e2.drain()
-            rows = capi.finalise_heaps(n, sc, od)
-            ok = list(T) == gold.final_T and all(
-                rows[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(oq.ntax))
-            parity = bool(ok)
+        if args.cpu_refs > 0:
+            cpu = cpu_baseline(O, gen, first, qseqs, qnames, args.mode, pool, args.nbest, args.cpu_warm, args.cpu_refs, args.cpu_refs_1thread)
+        if not args.no_parity:
+            parity = parity_on_timed_path(O, capi, pq, gen, first, qseqs, qnames, args.mode, pool, args.nbest, min(args.parity_refs, args.refs), local_rank, args.qt)
+    eng.close()
+
+    # ---- other resident-query counts, driver-timed in the same run (rank 0, N=1 only)
+    sweep = None
+    if rank == 0 and world == 1 and not emu and not args.no_sweep:
+        sweep = []
+        for nq_s, mode_s, steps_s in ((1, "iupac", 5), (4, "iupac", 5), (16, "iupac", 5), (10000, "acgt", 2)):
+            e = single_gpu_workload(hostlib, nq_s, args.sweep_refs, mode_s, args.nbest, args.sweep_refs if nq_s <= 16 else args.pool,
+                                    steps_s, 1, args.nchar, args.seed, args.preset, local_rank)
+            if (nq_s, args.sweep_refs, args.nchar, args.nbest, mode_s) == (10000, 1000000, 29903, 100, "acgt"):
+                e["workload"] = "BASELINE config[2]: " + e["workload"]
+            sweep.append(e)
 
     if rank == 0:
         out = {
@@ -293,6 +444,7 @@ def main():
             "multi_gpu": None if (world == 1 and not emu) else
             ("query shards: every GPU holds all %d references and the heaps of %d of the %d queries (column classes from the whole set); no data-path exchange%s; exact"
              % (local_refs, q1 - q0, pq.ntax, ", one all-reduced int per pool" if cons else "")) if shard_mode else
+            plan.describe() if multi == "refshard" else
             "block-cyclic slices of %d refs, concurrent scans, heap state (%d B in %d per-query-group blobs) pipelined rank to rank (RCCL isend/irecv), exact" % (pool, nbytes, world),
             "dtype": "u32 bit-planes / int32 counts", "data": "synthetic (seed %d, preset %d)" % (args.seed, args.preset),
             "config": {"workload": (("BASELINE config[1]: " if (pq.ntax, args.refs, args.nchar, args.nbest) == (1000, 100000, 29903, 100) else
@@ -300,24 +452,27 @@ def main():
                                     + "%d queries x %d refs/GPU x %d cols, %s, top-k %d, pool %d")
                                    % (pq.ntax, args.refs, args.nchar, "4-bit IUPAC planes" if args.mode == "iupac" else "2-bit + validity planes (--acgt)", args.nbest, pool),
                        "queries": pq.ntax, "refs_per_gpu": args.refs, "nchar": args.nchar, "nbest": args.nbest, "pool": pool,
-                       "mode": args.mode, "packed_bytes_per_ref": bytes_per_ref, "db_load_s": round(load_s, 2),
+                       "mode": args.mode, "packed_bytes_per_ref": packed_bytes, "db_load_s": round(load_s, 2),
                        "query_prepare_s": round(t_q1 - t_q0, 2), "engine_open_s": round(t_q2 - t_q1, 2)},
             "step_parts": {"includes_derived_planes": not args.search_only, "derived_planes_ms": round(derive_ms, 3), "scan_and_replay_ms": round(search_only_ms, 3),
-                           "derived_planes_kernel": {"kernel": "derive_all_kernel", "bound": "hbm", "read_bytes_per_ref": bytes_per_ref, "written_bytes_per_ref": eng.derived_bytes_per_ref(),
-                                                     "achieved": round(local_refs * (bytes_per_ref + eng.derived_bytes_per_ref()) / (derive_ms * 1e-3) / 1e9, 1) if (derive_ms > 0 and eng.derived_bytes_per_ref()) else None,
+                           "derived_planes_kernel": {"kernel": "derive_all_kernel", "bound": "hbm", "read_bytes_per_ref": packed_bytes, "written_bytes_per_ref": derived_bytes,
+                                                     "achieved": round(local_refs * (packed_bytes + derived_bytes) / (derive_ms * 1e-3) / 1e9, 1) if (derive_ms > 0 and derived_bytes) else None,
                                                      "peak": HBM_PEAK_GBS, "unit": "GB/s (reads + writes, host-timed over its launches)"},
                            "note": "a step = planes derived from the resident packed records for this query set (uvaia_gpu_db_rederive) + pair scan + ordered replay; "
-                                   "the two parts timed on their own after the timed region"},
+                                   "the two parts timed on their own after the timed region (N = 1 only)"},
             "roofline": roofline,
             "replay": {"admissions_per_step": admitted // max(1, args.steps + args.warmup + 1), "on_demand_per_step": demanded // max(1, args.steps + args.warmup + 1),
                        "dense_rescans_per_step": dense_rescans // max(1, args.steps + args.warmup + 1)},
             "cpu_baseline": cpu,
-            "parity_check_on_sample": parity,
+            "parity_check_on_timed_path": parity,
+            "sweep": sweep,
         }
         print(json.dumps(out))
-    eng.close()
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+    if parity is False:
+        raise SystemExit("bench.py: the timed path disagrees with the oracle on the sample")
 
 
 if __name__ == "__main__":

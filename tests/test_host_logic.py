@@ -189,6 +189,47 @@ def test_readfasta_streams_plain_gz_xz(tmp_path):
         assert got == want, kind
 
 
+def test_truncated_compressed_reference_is_an_error_not_a_short_database(tmp_path):
+    """A decompressor that dies in mid-stream looks like end of data to getline(): the reader must end the run with a message
+    (biomcmc_error), while a reader that is closed before its end of data (the tool then gets SIGPIPE) must not."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(3)
+    text = b"".join(b">r%d\n" % i + bytes(rng.choice(list(b"ACGT"), 3000).astype(np.uint8)) + b"\n" for i in range(400))
+    good, cut = tmp_path / "db.fa.xz", tmp_path / "cut.fa.xz"
+    with lzma.open(good, "wb") as fh: fh.write(text)
+    cut.write_bytes(good.read_bytes()[:-2000])
+    prog = ("import sys; sys.path.insert(0, %r); from uvaia_amd import hostlib as H; L = H.load_library()\n"
+            "r = L.new_readfasta(sys.argv[1].encode()); n = 0\n"
+            "while L.readfasta_next(r) >= 0:\n"
+            "    n += 1\n"
+            "    if len(sys.argv) > 2 and n == 3: break\n"
+            "L.del_readfasta(r); print('read', n)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ok = subprocess.run([sys.executable, "-c", prog, str(good)], capture_output=True, text=True)
+    assert ok.returncode == 0 and "read 400" in ok.stdout
+    early = subprocess.run([sys.executable, "-c", prog, str(good), "stop-early"], capture_output=True, text=True)
+    assert early.returncode == 0 and "read 3" in early.stdout
+    bad = subprocess.run([sys.executable, "-c", prog, str(cut)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "decompressor reported an error" in bad.stderr and "read" not in bad.stdout
+
+
+def test_query_alignment_length_follows_the_kept_sequences(tmp_path):
+    """The first query record is dropped (too short) and has another length than the kept ones: nchar must be theirs."""
+    seqs = [b"ACGT", b"ACGTACGTACGTACGTACGT", b"ACGTACGTACGTACGTACGA", b"ACGTACGTACGTACGTACCA"]
+    p = tmp_path / "q.fa"
+    p.write_bytes(b"".join(b">q%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    L = H.load_library()
+    L.read_fasta_alignment_from_file.restype = C.POINTER(H.Alignment)
+    L.read_fasta_alignment_from_file.argtypes = [C.c_char_p, C.c_int]
+    L.uvaia_keep_only_valid_sequences.argtypes = [C.POINTER(H.Alignment), C.c_double, C.c_bool]
+    L.del_alignment.argtypes = [C.POINTER(H.Alignment)]
+    aln = L.read_fasta_alignment_from_file(str(p).encode(), 0)
+    assert aln.contents.ntax == 4 and aln.contents.nchar == 4
+    L.uvaia_keep_only_valid_sequences(aln, 0.5, True)
+    assert aln.contents.ntax == 3 and aln.contents.nchar == 20
+    L.del_alignment(aln)
+
+
 def test_generator_is_deterministic_and_shaped():
     g = H.Synth(29903, seed=20241008, preset=0)
     a, na = g.generate(1000, 64)

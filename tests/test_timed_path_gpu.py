@@ -1,0 +1,176 @@
+"""The path bench.py times, checked in the regime it is timed in (`pytest -m gpu`).
+
+bench.py's step is uvaia_gpu_db_rederive (own stream) + uvaia_gpu_search_resident over an HBM-resident database with the default
+switches: at 1 000 queries that means the column-compressed scan with rare columns, pools cut into sub-slices that run several
+counter buffers ahead of the replay, and a replay that does not cache the query row in LDS.  The tests below send generator data
+of BASELINE config[1] / config[2] shape through exactly that sequence of calls and compare with the CPU oracle (heaps, tolerances,
+dump flags: src/nearest.c:288-306,479-510), then check at the full config[1] size what does not need the oracle to finish:
+the three ways of running the same search agree, and the scores the heaps hold are the oracle's pair scores.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from uvaia_amd import capi, hostlib
+
+pytestmark = pytest.mark.gpu
+
+QUERY_INDEX0 = 1 << 40          # as bench.py: queries and references come from disjoint sequence numbers of one generator
+
+
+def _names(n, p="r"):
+    return ["%s%d" % (p, i) for i in range(n)]
+
+
+def _want(gold, ntax):
+    return [[(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(ntax)]
+
+
+def _load(eng, gen, first, n, chunk=8192):
+    eng.db_reserve(n)
+    for a in range(0, n, chunk):
+        m = min(chunk, n - a)
+        rows, non_n = gen.generate(first + a, m)
+        eng.db_append_block(rows, non_n)
+
+
+def _timed_step(eng, pool):
+    """one bench.py step, with the dump flags read back"""
+    eng.reset()
+    eng.db_rederive()
+    ent = eng.search_resident(pool)
+    eng.sync()
+    n, T, sc, od = eng.drain()
+    return capi.finalise_heaps(n, sc, od), list(T), ent
+
+
+@pytest.fixture(scope="module")
+def config1_sample():
+    """1 000 generator queries x 8 000 generator references x 29 903 columns, k = 100, one pool (pool 65 536 > 8 000)."""
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(QUERY_INDEX0, 1000)
+    qn = _names(1000, "query_")
+    refs, _ = gen.generate_bytes(0, 8000)
+    oq = O.Query(qs, qn)
+    gold = O.search(oq, refs, _names(len(refs)), pool=8000, nbest=100, ambig_r=0.5)
+    return gen, qs, qn, refs, oq, gold
+
+
+def test_config1_regime_default_switches_equal_oracle(config1_sample):
+    """(a) db_append -> db_rederive -> search_resident with nothing forced: scan3_kernel with rare columns, replay without the LDS
+    query row (>= 256 queries), the rebuild of the derived planes overlapping the scan."""
+    gen, qs, qn, refs, oq, gold = config1_sample
+    pq = hostlib.PreparedQuery(qs, qn)
+    assert pq.ntax == oq.ntax == 1000
+    with pq.open_engine(nbest=100, max_pool=8000) as eng:
+        assert eng.scan_variant() == 2
+        _load(eng, gen, 0, len(refs))
+        for _ in range(2):                                   # a second step over the same resident database gives the same answer
+            rows, T, ent = _timed_step(eng, 8000)
+            assert rows == _want(gold, oq.ntax)
+            assert T == gold.final_T
+            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+        admitted, demanded, dense = eng.replay_stats(reset=True)
+        assert admitted > 100 * 1000                         # heaps fill and keep turning over: the regime of the benchmark
+
+
+def test_config1_regime_sub_slices_equal_oracle(config1_sample, monkeypatch):
+    """(a) the same search cut into five sub-slices that are not tile aligned (the 100 000-reference benchmark run cuts its pools
+    into three): scans run ahead of the replay in the ring of counter buffers, which wraps."""
+    gen, qs, qn, refs, oq, gold = config1_sample
+    monkeypatch.setenv("UVAIA_GPU_SUBSLICE", "1700")
+    pq = hostlib.PreparedQuery(qs, qn)
+    with pq.open_engine(nbest=100, max_pool=8000) as eng:
+        _load(eng, gen, 0, len(refs))
+        rows, T, ent = _timed_step(eng, 8000)
+        assert rows == _want(gold, oq.ntax) and T == gold.final_T
+        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+def test_config1_regime_streaming_push_equals_oracle(config1_sample):
+    """the reference-shaped boundary call (uvaia_gpu_push, one pool) on the same data"""
+    gen, qs, qn, refs, oq, gold = config1_sample
+    pq = hostlib.PreparedQuery(qs, qn)
+    with pq.open_engine(nbest=100, max_pool=8000) as eng:
+        ent = eng.push(refs)
+        n, T, sc, od = eng.drain()
+        assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
+        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+def test_config2_regime_acgt_many_query_tiles_equal_oracle():
+    """(b) --acgt with 2 048 queries (128 query tiles, the many-tile regime of BASELINE config[2]) x 3 000 references, k = 100,
+    through db_append -> db_rederive -> search_resident with the default switches."""
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(QUERY_INDEX0, 2048)
+    qn = _names(2048, "query_")
+    refs, _ = gen.generate_bytes(0, 3000)
+    oq = O.Query(qs, qn, acgt=True)
+    gold = O.search(oq, refs, _names(len(refs)), pool=3000, nbest=100, ambig_r=0.5)
+    pq = hostlib.PreparedQuery(qs, qn, acgt=True)
+    assert pq.ntax == oq.ntax
+    with pq.open_engine(nbest=100, max_pool=3000) as eng:
+        assert eng.scan_variant() == 2
+        _load(eng, gen, 0, len(refs))
+        rows, T, ent = _timed_step(eng, 3000)
+        assert rows == _want(gold, oq.ntax) and T == gold.final_T
+        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+def _heap_pairs(rows):
+    """{ordinal: [(query, scores)]} of everything the heaps hold"""
+    by_ref = {}
+    for iq, r in enumerate(rows):
+        for s, o in r:
+            by_ref.setdefault(o, []).append((iq, s))
+    return by_ref
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt, monkeypatch):
+    """(c) 1 000 queries x 100 000 references (BASELINE config[1]; also with --acgt), pool 65 536: the timed step (rederive on its
+    own stream overlapping three sub-slice scans), the same step with every launch serialised, and the streaming push path must
+    leave identical heaps, tolerances and dump flags; and the six scores of heap entries are the oracle's untruncated pair scores
+    (checked for every entry that refers to one of 192 sampled references)."""
+    n_ref, pool = 100000, 65536
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(QUERY_INDEX0, 1000)
+    qn = _names(1000, "query_")
+    pq = hostlib.PreparedQuery(qs, qn, acgt=acgt)
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:
+        _load(eng, gen, 0, n_ref)
+        rows, T, ent = _timed_step(eng, pool)
+        rows2, T2, ent2 = _timed_step(eng, pool)
+        assert rows2 == rows and T2 == T and np.array_equal(ent, ent2)
+    monkeypatch.setenv("UVAIA_GPU_SERIAL", "1")
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:
+        _load(eng, gen, 0, n_ref)
+        rows_s, T_s, ent_s = _timed_step(eng, pool)
+    monkeypatch.delenv("UVAIA_GPU_SERIAL")
+    assert rows_s == rows and T_s == T and np.array_equal(ent_s, ent)
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:              # streaming: two pools of raw characters
+        ent_p = []
+        for a in range(0, n_ref, pool):
+            m = min(pool, n_ref - a)
+            rows_b, non_n = gen.generate(a, m)
+            ent_p.append(eng.push([rows_b[i].tobytes() for i in range(m)], non_n=non_n, ordinal0=a))
+            del rows_b
+        n, Tp, sc, od = eng.drain()
+        assert capi.finalise_heaps(n, sc, od) == rows and list(Tp) == T
+        assert np.array_equal(np.concatenate(ent_p), ent)
+    # every heap is full, tolerances are those of the worst kept entries (src/nearest.c:506-508)
+    assert all(len(r) == 100 for r in rows)
+    # the heaps hold the oracle's scores
+    by_ref = _heap_pairs(rows)
+    assert set(by_ref) <= set(np.nonzero(ent)[0].tolist())             # whatever is kept at the end was dumped
+    rng = np.random.default_rng(5)
+    sample = sorted(rng.choice(sorted(by_ref), size=min(192, len(by_ref)), replace=False).tolist())
+    seqs = [gen.generate(o, 1)[0][0].tobytes() for o in sample]
+    oq = O.Query(qs, qn, acgt=acgt)
+    want = oq.allpairs(seqs)
+    checked = 0
+    for j, o in enumerate(sample):
+        for iq, s in by_ref[o]:
+            assert tuple(int(x) for x in want[j, iq]) == s, "reference %d, query %d" % (o, iq)
+            checked += 1
+    assert checked >= len(sample)

@@ -77,7 +77,10 @@ def test_round_trip(tmp_path, n, nchar):
     nt = tiles.shape[0]
     non_n = np.zeros(nt * 64, dtype=np.int32)
     non_n[:n] = [sum(ch not in b"N-?XO." for ch in s) for s in seqs]
-    side = np.arange(nt * 64 * SIDE_INTS, dtype=np.int32).reshape(nt * 64, SIDE_INTS)
+    n_words = ((nchar + 31) // 32 + 3) // 4 * 4
+    side = np.arange(nt * 64 * SIDE_INTS, dtype=np.int32).reshape(nt * 64, SIDE_INTS)      # plane words: any bits
+    side[:, 0] = np.arange(nt * 64) % 14                                                    # listed-word count (may exceed the 11 slots)
+    side[:, 1:12] = (np.arange(nt * 64)[:, None] + np.arange(11)[None, :]) % n_words        # word indices inside the alignment
     path = str(tmp_path / "db.uvdb").encode()
     w = L.uvdb_create(path, nchar, tiles[0].nbytes, SIDE_INTS, 0.5)
     assert w
@@ -124,6 +127,42 @@ def test_rejects_damaged_files(tmp_path):
         open(p, "wb").write(data)
         assert not L.uvdb_open(p.encode(), err, 256)
         assert err.value
+    # damage that keeps the size and the header: interior index entries, an unterminated name table, side rows and valid-site
+    # counts that point outside the alignment (these go to the device: the engine indexes planes with them)
+    h = Header.from_buffer_copy(raw[:C.sizeof(Header)])
+    off_nonn, off_side, off_name_idx, off_names, off_exc_idx = h.off[1], h.off[2], h.off[3], h.off[4], h.off[5]
+
+    def patched(at, value, fmt="<q"):
+        import struct
+        b = bytearray(raw)
+        b[at:at + struct.calcsize(fmt)] = struct.pack(fmt, value)
+        return bytes(b)
+
+    n_words = ((70 + 31) // 32 + 3) // 4 * 4
+    cases = {
+        "name_idx_interior_back": patched(off_name_idx + 8 * 2, 0),                 # name_idx[2] < name_idx[1]
+        "name_idx_interior_far": patched(off_name_idx + 8 * 1, 1 << 40),            # beyond the names section
+        "name_idx_first": patched(off_name_idx, 1),
+        "exc_idx_interior": patched(off_exc_idx + 8 * 1, 1 << 50),
+        "names_unterminated": patched(off_names + 2, ord("x"), "<B"),              # the NUL that ends "r0"
+        "side_word_outside": patched(off_side + 4 * 1, n_words, "<i"),              # first listed word of reference 0 ...
+        "side_count_negative": patched(off_side, -1, "<i"),
+        "non_n_above_nchar": patched(off_nonn, 71, "<i"),
+    }
+    cases["side_word_outside"] = patched(off_side, 1, "<i")[:off_side + 4] + patched(off_side + 4, n_words, "<i")[off_side + 4:]
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".uvdb"))
+        open(p, "wb").write(data)
+        err.value = b""
+        assert not L.uvdb_open(p.encode(), err, 256), name
+        assert err.value, name
+    # section sizes that would wrap 64 bits: n_ref, n_tiles huge with everything else in place
+    hb = bytearray(raw)
+    import struct
+    struct.pack_into("<QQ", hb, Header.n_ref.offset, (1 << 61) + 3, ((1 << 61) + 3 + 63) // 64)
+    p = str(tmp_path / "wrap.uvdb")
+    open(p, "wb").write(bytes(hb))
+    assert not L.uvdb_open(p.encode(), err, 256)
     # a writer that was given names but not their tiles does not produce a file that claims to be complete
     w = L.uvdb_create(str(tmp_path / "incomplete.uvdb").encode(), 70, tiles[0].nbytes, SIDE_INTS, 0.5)
     L.uvdb_add_reference(w, b"r0", seqs[0])

@@ -229,7 +229,7 @@ file_compress_t
 biomcmc_open_compress (const char *path, const char *mode)
 {
   file_compress_t fc = (file_compress_t) biomcmc_malloc (sizeof (struct file_compress_struct));
-  fc->filename = strdup (path); fc->fp = NULL; fc->piped = 0;
+  fc->filename = strdup (path); fc->fp = NULL; fc->piped = 0; fc->writing = (mode[0] != 'r'); fc->at_eof = 0;
   char *quoted = shell_quote (path), *cmd = (char *) biomcmc_malloc (strlen (quoted) + 64);
   if (mode[0] == 'r') {
     const char *tool = decompressor_for (path);
@@ -254,7 +254,17 @@ void
 biomcmc_close_compress (file_compress_t fc)
 {
   if (!fc) return;
-  if (fc->fp) { if (fc->piped) pclose (fc->fp); else fclose (fc->fp); }
+  int status = 0;
+  if (fc->fp) status = fc->piped ? pclose (fc->fp) : fclose (fc->fp);
+  /* A decompressor that fails in the middle of a stream looks like end of data to getline(): a search over a truncated or
+   * corrupt reference file must not pass for a complete one.  (A reader closed before its end of data kills the tool with
+   * SIGPIPE: that is not an error.)  A failing compressor (disk full, killed xz) leaves an unusable output file: say so. */
+  if (status != 0 && !fc->writing && fc->at_eof) {
+    char *name = strdup (fc->filename);
+    free (fc->filename); free (fc);
+    biomcmc_error ("reading %s failed: the decompressor reported an error (truncated or corrupt file?)", name);
+  }
+  if (status != 0 && fc->writing) biomcmc_warning ("writing %s failed: the compressor or the file system reported an error\n", fc->filename);
   free (fc->filename); free (fc);
 }
 
@@ -262,7 +272,7 @@ int
 biomcmc_getline_compress (char **lineptr, size_t *n, file_compress_t fc)
 {
   ssize_t got = getline (lineptr, n, fc->fp);
-  if (got < 0) return -1;
+  if (got < 0) { fc->at_eof = 1; return -1; }
   while (got > 0 && ((*lineptr)[got - 1] == '\n' || (*lineptr)[got - 1] == '\r')) (*lineptr)[--got] = '\0';   /* lines come back without their terminator */
   return (int) got;
 }

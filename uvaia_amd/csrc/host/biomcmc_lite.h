@@ -39,6 +39,7 @@ struct file_compress_struct {
   char *filename;
   FILE *fp;
   int piped;           /* fp comes from popen() */
+  int writing, at_eof; /* opened for writing; a read hit end of data (then a failing decompressor means truncated input) */
 };
 
 /* memory / diagnostics (biomcmc_error = message + exit, biomcmc_warning = message and continue) */

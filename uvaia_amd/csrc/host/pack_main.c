@@ -82,12 +82,13 @@ main (int argc, char **argv)
           w = uvdb_create (out, nchar, tb, uvaia_gpu_db_side_row_ints (), ambig_r);
           if (!w) biomcmc_error ("cannot create %s", out);
         }
+        /* as the reference's fill loop (src/nearest.c:263-278): low-quality records are dropped first, only then must the length fit */
+        const int nn = quick_count_sequence_non_N (rfas->seq, rfas->seqlength);
+        if (nn < non_n_ref) { n_invalid++; continue; }
         if (rfas->seqlength != (size_t) nchar) {
           biomcmc_warning ("Reference sequence '%s' has %zu sites but the first sequence has %d sites\n", rfas->name, rfas->seqlength, nchar);
           biomcmc_error ("all sequences must be aligned");
         }
-        const int nn = quick_count_sequence_non_N (rfas->seq, rfas->seqlength);
-        if (nn < non_n_ref) { n_invalid++; continue; }
         if (uvdb_add_reference (w, rfas->name, rfas->seq)) biomcmc_error ("out of memory while indexing %s", rfas->name);
         non_n[fill] = nn;
         seq[fill++] = rfas->seq; rfas->seq = NULL;

@@ -62,6 +62,9 @@ uvaia_keep_only_valid_sequences (alignment aln, double ambiguity, bool check_ali
     biomcmc_warning ("Reference sequences in file %s are not aligned.\n", aln->filename);
     biomcmc_error ("You can use uvaialign (or mafft, or minimap2) to align them against the same reference.");
   }
+  /* aln->nchar is the length of the FIRST record of the file; if that record was dropped above and the kept ones are longer or
+   * shorter, trim, idx and the packed query rows would be laid out for the wrong length (reads past the end of every row) */
+  if (n_kept && common_length > 0) aln->nchar = (int) common_length;
   char_vector_reduce_to_valid_strings (aln->character, kept, n_kept);
   char_vector_reduce_to_valid_strings (aln->taxlabel, kept, n_kept);
   aln->ntax = n_kept;

@@ -193,11 +193,21 @@ uvdb_open (const char *filename, char *errbuf, size_t errlen)
     set_err (errbuf, errlen, "%s is not a packed uvaia database (version 1)", filename);
     uvdb_close_reader (r); return NULL;
   }
-  const uint64_t n = h->n_ref;
-  if (h->file_bytes != (uint64_t) r->map_len || h->n_tiles != (n + 63) / 64 || h->tile_bytes != (uint64_t) h->W4 * 4 * 64 * 16 ||
-      h->W4 != ((h->nchar + 31) / 32 + 3) / 4 || h->off_planes + h->n_tiles * h->tile_bytes > h->off_nonn ||
-      h->off_nonn + h->n_tiles * 64 * 4 > h->off_side || h->off_side + h->n_tiles * 64 * (uint64_t) h->side_row_ints * 4 > h->off_name_idx ||
-      h->off_name_idx + (n + 1) * 8 > h->off_names || h->off_names > h->off_exc_idx || h->off_exc_idx + (n + 1) * 8 > h->off_exc || h->off_exc > h->file_bytes) {
+  const uint64_t n = h->n_ref, flen = (uint64_t) r->map_len;
+  /* every section size is computed with overflow checks: a hostile header must not wrap a product into a small number */
+  uint64_t sz_planes = 0, sz_nonn = 0, sz_side = 0, sz_idx = 0;
+  int bad = h->file_bytes != flen || n > (UINT64_MAX >> 8) || h->n_tiles != (n + 63) / 64 || h->nchar == 0 ||
+            h->W4 != ((h->nchar + 31) / 32 + 3) / 4 || h->tile_bytes != (uint64_t) h->W4 * 4 * 64 * 16 || h->side_row_ints != UVDB_SIDE_ROW_INTS;
+  bad = bad || __builtin_mul_overflow (h->n_tiles, h->tile_bytes, &sz_planes) || __builtin_mul_overflow (h->n_tiles, (uint64_t) 64 * 4, &sz_nonn) ||
+        __builtin_mul_overflow (h->n_tiles, (uint64_t) 64 * 4 * h->side_row_ints, &sz_side) || __builtin_mul_overflow (n + 1, (uint64_t) 8, &sz_idx);
+  /* sections in file order, each inside the file and in front of the next one */
+  bad = bad || h->off_planes < sizeof (struct uvdb_header) || h->off_planes > flen || sz_planes > flen - h->off_planes || h->off_planes + sz_planes > h->off_nonn ||
+        h->off_nonn > flen || sz_nonn > flen - h->off_nonn || h->off_nonn + sz_nonn > h->off_side ||
+        h->off_side > flen || sz_side > flen - h->off_side || h->off_side + sz_side > h->off_name_idx ||
+        h->off_name_idx > flen || sz_idx > flen - h->off_name_idx || h->off_name_idx + sz_idx > h->off_names ||
+        h->off_names > h->off_exc_idx || h->off_exc_idx > flen || sz_idx > flen - h->off_exc_idx || h->off_exc_idx + sz_idx > h->off_exc || h->off_exc > flen ||
+        (h->off_planes | h->off_nonn | h->off_side | h->off_name_idx | h->off_exc_idx | h->off_exc) % 8 != 0;
+  if (bad) {
     set_err (errbuf, errlen, "%s is truncated or inconsistent", filename);
     uvdb_close_reader (r); return NULL;
   }
@@ -206,9 +216,32 @@ uvdb_open (const char *filename, char *errbuf, size_t errlen)
   r->names = (const char *) (r->map + h->off_names);
   r->exc_idx = (const uint64_t *) (r->map + h->off_exc_idx);
   r->exc = (const uvdb_exc *) (r->map + h->off_exc);
-  if (h->off_names + r->name_idx[n] > h->off_exc_idx || h->off_exc + r->exc_idx[n] * sizeof (uvdb_exc) != h->file_bytes) {
-    set_err (errbuf, errlen, "%s has inconsistent index sections", filename);
-    uvdb_close_reader (r); return NULL;
+  {  /* the two index arrays: start at 0, never decrease, end inside their sections; every name ends in NUL inside the names section */
+    const uint64_t names_len = h->off_exc_idx - h->off_names, exc_cap = (flen - h->off_exc) / sizeof (uvdb_exc);
+    int ok = r->name_idx[0] == 0 && r->exc_idx[0] == 0 && r->name_idx[n] <= names_len && r->exc_idx[n] <= exc_cap &&
+             h->off_exc + r->exc_idx[n] * sizeof (uvdb_exc) == flen;
+    for (uint64_t i = 0; ok && i < n; i++)
+      ok = r->name_idx[i] < r->name_idx[i + 1] && r->name_idx[i + 1] <= names_len && r->exc_idx[i] <= r->exc_idx[i + 1] && r->exc_idx[i + 1] <= exc_cap &&
+           r->names[r->name_idx[i + 1] - 1] == '\0';
+    if (!ok) {
+      set_err (errbuf, errlen, "%s has inconsistent index sections", filename);
+      uvdb_close_reader (r); return NULL;
+    }
+  }
+  {  /* what goes to the device unchecked otherwise: valid-site counts within the alignment, side rows that list words of the alignment
+      * (a count above the capacity only says "incomplete", as the engine writes it) */
+    const uint32_t n_words = h->W4 * 4;
+    const int32_t *side = (const int32_t *) (r->map + h->off_side);
+    int ok = 1;
+    for (uint64_t i = 0; ok && i < n; i++) {
+      const int32_t *row = side + i * h->side_row_ints;
+      ok = r->non_n[i] >= 0 && (uint32_t) r->non_n[i] <= h->nchar && row[0] >= 0;
+      for (int k = 0; ok && k < UVDB_SIDE_LISTED && k < row[0]; k++) ok = row[1 + k] >= 0 && (uint32_t) row[1 + k] < n_words;
+    }
+    if (!ok) {
+      set_err (errbuf, errlen, "%s holds valid-site counts or ambiguity rows outside the alignment", filename);
+      uvdb_close_reader (r); return NULL;
+    }
   }
   return r;
 }

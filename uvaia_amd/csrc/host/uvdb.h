@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 #define UVDB_MAGIC "UVAIADB1"
+#define UVDB_SIDE_ROW_INTS 64   /* ints per side row: [0] count, [1..11] listed alignment words, [12 + 4k + p] plane p of the k-th listed word (uvaia_gpu_db_side_row_ints()) */
+#define UVDB_SIDE_LISTED 11
 
 struct uvdb_header {
   char magic[8];

@@ -1057,6 +1057,9 @@ int uvaia_gpu_db_append_packed(uvaia_gpu_ctx *c, const void *planes, const int *
     hipFree(d_tmp);
   }
   HIPCHK(c, hipMemcpyAsync(c->d_db_nonn + (size_t)t0 * 64, non_n, n_tiles * 64 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(sanitise_import_kernel, dim3((unsigned)((n_tiles * 64 + 255) / 256)), dim3(256), 0, c->stream, c->acgt ? (int *)nullptr : c->d_db_amb + (size_t)t0 * 64 * AMB_ROW,
+                     c->d_db_nonn + (size_t)t0 * 64, (long long)(n_tiles * 64), c->W4 * 4, c->nchar);
+  HIPCHK(c, hipGetLastError());
   int rc = derive_rows(c, c->d_db, (long long)c->db_n, n_ref); if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->db_n += (size_t)n_ref;

@@ -59,9 +59,14 @@ class TorchComm:
 
 
 class TorchStateBuffer:
+    """Raw bytes the engine exports a state range into / imports it from.  Uninitialised on purpose: the engine writes or the
+    transport fills the whole range, and a fill kernel on torch's stream would not be ordered against the engine's own streams."""
+
     def __init__(self, nbytes, device):
         import torch
-        self.tensor = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.tensor = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if device != "cpu":
+            torch.cuda.current_stream().synchronize()      # the allocation itself may queue work on torch's stream
         self.ptr = self.tensor.data_ptr()
 
 
@@ -166,10 +171,23 @@ def run_ring_grouped(engine, comm, rank, world, slices, n_query, cons, make_buff
     # Receives are posted in program order, right before they are needed (never ahead of this rank's own sends): if the
     # backend serialises all point-to-point operations of a process group on one stream, a receive posted early would
     # hold up the sends queued behind it.  Sends are non-blocking; the wrap-around link has its own process group.
-    sends = []
+    sends = []                     # (buffer, work) of sends that may still be reading their buffer
+    free_out = {}                  # size -> buffers whose send has completed (recycled: memory stays bounded by the sends in flight)
+    recv_buf = {}                  # one receive buffer per group size: state_import_range returns once the engine has read it
+
+    def out_buffer(nbytes):
+        for i in range(len(sends) - 1, -1, -1):
+            if sends[i][1].is_completed():
+                b, _ = sends.pop(i)
+                free_out.setdefault(b.tensor.numel(), []).append(b)
+        pool = free_out.get(nbytes)
+        return pool.pop() if pool else make_buffer(nbytes)
 
     def receive(s, j, q0, q1):
-        buf = make_buffer(engine.state_range_bytes(q0, q1))
+        nb = engine.state_range_bytes(q0, q1)
+        buf = recv_buf.get(nb)
+        if buf is None:
+            buf = recv_buf[nb] = make_buffer(nb)
         comm.wait(comm.irecv(buf, src))
         engine.state_import_range(buf.ptr, q0, q1)
 
@@ -188,7 +206,7 @@ def run_ring_grouped(engine, comm, rank, world, slices, n_query, cons, make_buff
             take_snapshot = (rank == 0 and j == 0 and (cons or s == 0))
             engine.slice_replay_range(s & 1, slices[s].ordinal0, q0, q1, take_snapshot)
             if not (rank == world - 1 and s == n - 1):
-                out = make_buffer(engine.state_range_bytes(q0, q1))
+                out = out_buffer(engine.state_range_bytes(q0, q1))
                 engine.state_export_range(out.ptr, q0, q1)
                 sends.append((out, comm.isend(out, dst)))
     for out, work in sends:

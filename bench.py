@@ -49,7 +49,7 @@ def parse(argv=None):
     ap.add_argument("--qt", type=int, default=0, help="query tile of the scan kernel (8/16/32, 0 = default)")
     ap.add_argument("--cpu-refs", type=int, default=8192, help="references in the timed CPU-baseline sample (0 = skip), after --cpu-warm untimed ones")
     ap.add_argument("--cpu-warm", type=int, default=2048, help="references fed to the CPU baseline before its timed sample (heaps full, tolerances settled)")
-    ap.add_argument("--cpu-refs-1thread", type=int, default=256, help="timed sample of the single-thread CPU baseline (same warm state)")
+    ap.add_argument("--cpu-refs-1thread", type=int, default=512, help="timed sample of the single-thread CPU baseline (same warm state)")
     ap.add_argument("--parity-refs", type=int, default=1536, help="references of the in-run GPU-vs-oracle check")
     ap.add_argument("--multi", choices=["shards", "ring", "refshard"], default="refshard",
                     help="N > 1: 'refshard' = every GPU derives and scans 1/N of the references against all queries, the pair counters "
@@ -59,6 +59,9 @@ def parse(argv=None):
     ap.add_argument("--emulate-shard-of", type=int, default=0, metavar="N",
                     help="single process: do the work of rank 0 of N query shards (whole stream of N x --refs references, 1/N of the queries) "
                          "to measure the per-rank time of an N-GPU run on one GPU; the line is marked as emulated")
+    ap.add_argument("--emulate-refshard", type=int, default=0, metavar="N",
+                    help="single process, one GPU: N contexts run the reference-shard protocol of an N-GPU run (N x --refs references in all; "
+                         "peer copies instead of RCCL); the contexts share the card, so the step time / N estimates one rank's step")
     ap.add_argument("--search-only", action="store_true",
                     help="leave the per-query-set planes of the resident database as the load built them (the timed step then "
                          "holds scan + replay only); by default every step rebuilds them first")
@@ -208,7 +211,7 @@ def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_time
     L = O.lib()
     oq = O.Query(qseqs, qnames, acgt=(mode == "acgt"))
     cores = L.orc_max_threads()
-    bpool = 512                                         # batches small enough that the timed feed does the work, as --pool 512 would
+    bpool = 256                                         # batches small enough that every timed feed ends on a processed batch, as --pool 256 would
     s = L.orc_search_new(oq.ptr, bpool, nbest, 0.5, 0)
 
     def feed(a, n):
@@ -219,6 +222,7 @@ def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_time
         assert rc == 0
         return time.perf_counter() - t0
 
+    n_warm, n_timed, n_one = [(x + bpool - 1) // bpool * bpool for x in (n_warm, n_timed, n_one)]      # whole batches only
     try:
         feed(0, n_warm)
         t_all = feed(n_warm, n_timed)
@@ -263,8 +267,54 @@ def parity_on_timed_path(O, capi, pq, gen, first, qseqs, qnames, mode, pool, nbe
                 and all(got[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(oq.ntax)))
 
 
+def emulate_refshard(args):
+    """N contexts on one GPU run the protocol an N-GPU run uses (uvaia_gpu_group_*): every context derives and scans its pieces of the
+    N x --refs references against all queries, the rows of each query shard are copied to the context that replays them.  The
+    contexts share one card, so a step takes the SUM of the ranks' work: step / N estimates one rank's step on its own GPU (the
+    copies are device-local here; on the node they cross xGMI)."""
+    import torch
+    from uvaia_amd import capi, hostlib, refshard
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    n = args.emulate_refshard
+    gen = hostlib.Synth(args.nchar, seed=args.seed, preset=args.preset)
+    qseqs, _ = gen.generate_bytes(QUERY_INDEX0, args.queries)
+    pq = hostlib.PreparedQuery(qseqs, ["query_%d" % i for i in range(args.queries)], acgt=(args.mode == "acgt"))
+    plan = refshard.Plan(n, 0, args.refs, pq.ntax, pool=args.pool)
+    total = n * args.refs
+    g = capi.Group(pq, [0] * n, nbest=args.nbest, max_pool=plan.piece, piece_refs=plan.piece)
+    g.db_reserve(total)
+    for a in range(0, total, 4096):
+        m = min(4096, total - a)
+        rows, non_n = gen.generate(a, m)
+        g.db_append([rows[i].tobytes() for i in range(m)], non_n)
+
+    def step():
+        g.reset()
+        g.db_rederive()
+        g.search_resident(min(args.pool, total), want_entered=False)
+        g.sync()
+
+    step()
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    ms = 1e3 * elapsed / max(1, args.steps)
+    print(json.dumps({"metric": "ref-seqs scored/sec", "emulated": "reference shards: %d contexts on one GPU (uvaia_gpu_group_*), %d references in all; the contexts share the card: "
+                      "step_ms / %d estimates one rank's step on its own GPU" % (n, total, n),
+                      "n_contexts": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step_all_contexts_on_one_gpu": round(ms, 3), "estimated_ms_per_rank_step": round(ms / n, 3),
+                      "estimated_value_on_%d_gpus" % n: round(total / (ms / n * 1e-3), 1), "unit": "ref-seqs/s", "piece_refs": plan.piece,
+                      "config": {"workload": "%d queries x %d refs/GPU x %d cols, %s, top-k %d" % (pq.ntax, args.refs, args.nchar, args.mode, args.nbest)}}))
+    g.close()
+
+
 def main():
     args = parse()
+    if args.emulate_refshard > 1:
+        return emulate_refshard(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         launch_ranks(args)                       # does not return
@@ -305,19 +355,23 @@ def main():
     emu = args.emulate_shard_of if (world == 1 and args.emulate_shard_of > 1) else 0
     multi = args.multi if world > 1 else ("shards" if emu else None)
     shard_mode = multi == "shards"
-    local_refs = (emu or world) * args.refs if shard_mode else args.refs      # query shards: every rank holds (and scans) the whole stream
+    # query shards: every rank holds (and scans) the whole stream; reference shards: every rank holds the packed planes of the whole stream
+    # (the replay reads them) but derives and scans only its own pieces
+    local_refs = (emu or world) * args.refs if (shard_mode or multi == "refshard") else args.refs
     pool = min(args.pool, local_refs)
     from uvaia_amd import ring, shards
     on_gpu = backend == "nccl"
     plan = None
     if multi == "refshard":
         from uvaia_amd import refshard
-        plan = refshard.Plan(world, rank, args.refs, pq.ntax)
+        plan = refshard.Plan(world, rank, args.refs, pq.ntax, pool=args.pool)
         pool = plan.slice_refs
     eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank)
     t_q2 = time.time()
     if args.qt:
         eng.set_query_tile(args.qt)
+    if multi == "refshard":
+        eng.db_set_shard(rank, world, plan.piece)
     eng.db_reserve(local_refs)
     t0 = time.time()
     # ring: block-cyclic shard, stripe s (= one pool of world*pool references of the stream) = slice s of rank 0, 1, ...
@@ -342,7 +396,7 @@ def main():
     cons = len(pq.idx_c) > 0
     q0, q1 = shards.query_shard(pq.ntax, rank, emu or world) if shard_mode else (0, pq.ntax)
     allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons and dist is not None) else None
-    xchg = refshard.TorchExchange(dist, plan, eng, "cuda" if on_gpu else "cpu") if multi == "refshard" else None
+    xchg = refshard.TorchExchange(dist, plan, eng, "cuda" if on_gpu else "cpu", pinned=not on_gpu) if multi == "refshard" else None
 
     # ---- timed region
     # One step = everything one search of the resident database costs for this query set: the planes derived from the packed
@@ -406,7 +460,7 @@ def main():
     value = (emu or world) * args.refs * args.steps / elapsed
 
     # ---- roofline of the dominant kernel (pair scan): algorithmic bytes per launch / mean launch time (HIP events on its stream)
-    roofline = roofline_of(eng, scan_ms, scan_launches, float(local_refs) * args.steps, args.nchar, args.mode, pq.ntax)
+    roofline = roofline_of(eng, scan_ms, scan_launches, float(args.refs if multi == "refshard" else local_refs) * args.steps, args.nchar, args.mode, pq.ntax)
     if world == 1 and not emu:
         attach_pmc_traffic(roofline, pq.ntax, args.refs, pool, args.mode)
     derived_bytes = eng.derived_bytes_per_ref()

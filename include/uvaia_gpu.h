@@ -168,6 +168,57 @@ int uvaia_gpu_set_active_queries (uvaia_gpu_ctx *ctx, int q0, int q1);
 int uvaia_gpu_max_tolerance (uvaia_gpu_ctx *ctx, int *out);
 int uvaia_gpu_search_resident_pool (uvaia_gpu_ctx *ctx, size_t first, size_t n, int64_t ordinal0, int snapshot);
 
+/* ---- reference shards: several GPUs, each deriving and scanning 1/N of the references against ALL queries and replaying 1/N of
+ * the queries over ALL references (the default layout for several GPUs; DESIGN.md "Multi-GPU").  The scores of a pair do not
+ * depend on anything but the pair, so the scan -- more than nine tenths of a search -- shards by reference; the gate + heap machine
+ * of a query is sequential in stream order (src/nearest.c:488,504-508) but independent of the other queries, so the replay shards
+ * by query; in between, the pair counters of a slice move once: rank r sends to rank d the rows of d's queries (one all-to-all per
+ * slice over RCCL between processes -- uvaia_amd/refshard.py -- or peer copies inside one process -- uvaia_gpu_group_*).
+ *   - the stream is dealt in pieces of piece_refs references (a whole number of tiles of 64); piece p belongs to rank p % world
+ *   - every rank holds the PACKED planes of all references (query-independent; the replay reads a few words of the references
+ *     that reach a heap), but the planes derived for the query set -- and all scanning -- only for its own pieces
+ *   - the one coupling between queries, the batch snapshot cq->max_incompatible = max over ALL heaps (src/nearest.c:290-291), is
+ *     exchanged per batch when it can matter (query sets with constant-and-complete columns): uvaia_gpu_max_tolerance on the
+ *     active queries of every rank, maximum over the ranks, uvaia_gpu_set_snapshot.
+ * set_shard: before the database is reserved.  shard_scan: references [first, first+n) inside ONE owned piece, n <= max_pool;
+ *   cnt  int2 [uvaia_gpu_shard_rows()][tiles * 64]   pair counters as the scan kernels write them, row = query, a reference in
+ *                                                    column (position - 64 * (first / 64)); tiles = tiles the range touches
+ *   tmin int2 [uvaia_gpu_shard_rows()][tiles]        the two bounds per (query, tile) the replay skips tiles by
+ *   both caller-owned device buffers; asynchronous on the scan stream, uvaia_gpu_scan_wait() returns when they are complete.
+ * shard_replay: gate + heaps of queries [q0, q1) over references [first, first+n) (any rank's piece) from buffers of the same
+ *   layout that hold ONLY the rows q0 .. q1-1; pieces must be replayed in stream order; asynchronous (uvaia_gpu_sync). */
+int uvaia_gpu_db_set_shard (uvaia_gpu_ctx *ctx, int rank, int world, size_t piece_refs);
+int uvaia_gpu_shard_rows (const uvaia_gpu_ctx *ctx);
+int uvaia_gpu_shard_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, void *cnt, void *tmin);
+int uvaia_gpu_scan_wait (uvaia_gpu_ctx *ctx);
+int uvaia_gpu_replay_wait (uvaia_gpu_ctx *ctx);      /* replays issued so far are complete: their counter buffers may be overwritten */
+int uvaia_gpu_set_snapshot (uvaia_gpu_ctx *ctx, int snapshot);
+int uvaia_gpu_shard_replay (uvaia_gpu_ctx *ctx, const void *cnt, const void *tmin, size_t first, size_t n, int64_t ordinal0, int q0, int q1);
+
+/* ---- a group of contexts driven by ONE host thread (the command line's --devices): the reference-shard protocol with peer copies
+ * as the exchange; replaces the batch loop of src/nearest.c:245-330 for several GPUs.  devices[i] = HIP device of member i (a
+ * device may be listed more than once); piece_refs = 0 picks a default.  Calls mirror the single-context ones: the database is
+ * appended to every member, search_resident / push run the sharded search, drain collects every query's heap from the member
+ * that replays it.  A group of one device is a plain context. */
+typedef struct uvaia_gpu_group uvaia_gpu_group;
+int  uvaia_gpu_group_open (uvaia_gpu_group **group, const uvaia_gpu_query *query, int heap_size, const int *devices, int n_devices, size_t max_pool, size_t piece_refs);
+void uvaia_gpu_group_close (uvaia_gpu_group *group);
+const char *uvaia_gpu_group_last_error (const uvaia_gpu_group *group);     /* group may be NULL: error of the last failed open */
+int  uvaia_gpu_group_size (const uvaia_gpu_group *group);
+uvaia_gpu_ctx *uvaia_gpu_group_member (uvaia_gpu_group *group, int i);
+int  uvaia_gpu_group_query_shard (const uvaia_gpu_group *group, int i, int *q0, int *q1);
+int  uvaia_gpu_group_db_reserve (uvaia_gpu_group *group, size_t n_ref_capacity);
+int  uvaia_gpu_group_db_append (uvaia_gpu_group *group, const char *const *seq, const int *non_n, int n_ref);
+int  uvaia_gpu_group_db_append_packed (uvaia_gpu_group *group, const void *planes, const int *non_n, const int *side_rows, int n_ref);
+int  uvaia_gpu_group_db_clear (uvaia_gpu_group *group);
+int  uvaia_gpu_group_db_rederive (uvaia_gpu_group *group);
+size_t uvaia_gpu_group_db_size (const uvaia_gpu_group *group);
+int  uvaia_gpu_group_reset (uvaia_gpu_group *group);
+int  uvaia_gpu_group_search_resident (uvaia_gpu_group *group, size_t pool, int64_t ordinal0, uint8_t *entered);
+int  uvaia_gpu_group_push (uvaia_gpu_group *group, const char *const *seq, const int *non_n, int n_ref, int64_t ordinal0, uint8_t *entered);
+int  uvaia_gpu_group_drain (uvaia_gpu_group *group, int *n_items, int *max_incompatible, int *scores, int64_t *ordinals);
+int  uvaia_gpu_group_sync (uvaia_gpu_group *group);
+
 /* ---- packed interchange form (packed on-disk database).  Replaces, for a database that was packed once,
  * the serial text path of the reference (readfasta_next src/fastaseq.c:422-474 + the slot filling of src/nearest.c:251-286 +
  * quick_count_sequence_non_N src/fastaseq.c:642-648): tiles of 64 references, each uvaia_gpu_db_tile_bytes() long, laid out

@@ -53,6 +53,8 @@ def files(tmp_path_factory, bundled_db):
     (["--acgt"], {"acgt": True}),
     (["--trim", "230", "-x"], {"trim": 230, "exclude_self": True}),
     (["-k", "-n", "1"], {"keep_resolved": True, "nbest": 1}),
+    (["--devices", "0,0"], {}),                                                        # two contexts on one GPU: reference shards from the C host
+    (["--acgt", "--trim", "230", "--devices", "0,0,0"], {"acgt": True, "trim": 230}),
 ])
 def test_uvaia_cli_matches_oracle(files, extra, kw):
     d, qn, qs, rnames, rseqs = files
@@ -142,7 +144,7 @@ def test_uvaiaball_cli_matches_oracle(files):
 UVAIAPACK = os.path.join(ROOT, "bin", "uvaiapack")
 
 
-@pytest.mark.parametrize("extra", [[], ["--acgt"], ["--trim", "230", "-k"], ["-x"], ["-x", "--acgt", "-n", "3"]])
+@pytest.mark.parametrize("extra", [[], ["--acgt"], ["--trim", "230", "-k"], ["-x"], ["-x", "--acgt", "-n", "3"], ["--devices", "0,0"], ["--acgt", "--devices", "0,0,0"]])
 def test_packed_database_gives_the_same_files_as_the_text_path(files, extra):
     """`uvaiapack` + `uvaia --packed` against `uvaia -r` on the same references (two files, one xz, with gaps,
     ambiguity codes and sequences the -A filter drops): identical table and identical dump, byte for byte."""

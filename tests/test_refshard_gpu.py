@@ -1,0 +1,101 @@
+"""Reference shards on the GPU (`pytest -m gpu`): several contexts on ONE card run the protocol the driver's 8-GPU run uses --
+each context derives and scans only its pieces of the stream against all queries, the rows of each query shard are copied to the
+context that replays those queries (peer copies inside uvaia_gpu_group_*; all_to_all_single between processes), and the union of
+the contexts' heaps must equal the oracle's single loop (src/nearest.c:245-330): heaps, tolerances and dump flags."""
+import numpy as np
+import pytest
+
+import fixtures as F
+import oracle_lib as O
+from uvaia_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(n, p="r"):
+    return ["%s%d" % (p, i) for i in range(n)]
+
+
+def _want(gold, ntax):
+    return [[(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(ntax)]
+
+
+@pytest.fixture(scope="module")
+def data():
+    refs, root, cols = F.synth_alignment(1500, 2500, seed=21)
+    qs, _, _ = F.synth_alignment(70, 2500, seed=22, root=root, poly_cols=cols)
+    gappy = [bytearray(s) for s in qs]
+    for i, s in enumerate(gappy[:10]):           # every column invalid in some query: no constant-and-complete column
+        a = i * 250
+        s[a:a + 251] = b"N" * len(s[a:a + 251])
+    return refs, qs, [bytes(s) for s in gappy]
+
+
+@pytest.mark.parametrize("world,piece", [(2, 128), (3, 64), (4, 192)])
+@pytest.mark.parametrize("acgt,gappy,pool", [(False, False, 512), (True, False, 300), (False, True, 256), (True, True, 1500)])
+def test_group_of_contexts_on_one_gpu_equals_oracle(data, world, piece, acgt, gappy, pool):
+    refs, qs, qs_gappy = data
+    q = O.Query(qs_gappy if gappy else qs, _names(70, "q"), acgt=acgt)
+    assert (len(q.idx_c) > 0) == (not gappy)
+    gold = O.search(q, refs, _names(len(refs)), pool=pool, nbest=12, ambig_r=1.0)
+    with capi.Group(q, [0] * world, nbest=12, max_pool=max(pool, piece), piece_refs=piece) as g:
+        assert [g.query_shard(i) for i in range(world)][0][0] == 0
+        g.db_reserve(len(refs))
+        g.db_append(refs[:700]); g.db_append(refs[700:])
+        for _ in range(2):                        # a second search over the same resident database gives the same answer
+            g.reset()
+            g.db_rederive()
+            ent = g.search_resident(pool)
+            n, T, sc, od = g.drain()
+            assert capi.finalise_heaps(n, sc, od) == _want(gold, q.ntax)
+            assert list(T) == gold.final_T
+            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+def test_group_push_streams_batches_like_one_context(data, acgt):
+    """the reference-shaped call: one pool of raw sequences per push"""
+    refs, qs, _ = data
+    q = O.Query(qs, _names(70, "q"), acgt=acgt)
+    pool = 400
+    gold = O.search(q, refs, _names(len(refs)), pool=pool, nbest=7, ambig_r=1.0)
+    with capi.Group(q, [0, 0, 0], nbest=7, max_pool=pool, piece_refs=64) as g:
+        ent = [g.push(refs[a:a + pool], ordinal0=a) for a in range(0, len(refs), pool)]
+        n, T, sc, od = g.drain()
+    assert capi.finalise_heaps(n, sc, od) == _want(gold, q.ntax) and list(T) == gold.final_T
+    assert list(np.nonzero(np.concatenate(ent))[0]) == list(gold.saved)
+
+
+def test_group_at_benchmark_shape():
+    """generator data, 1 000 queries x 12 000 references x 29 903 columns, k = 100, four contexts: the regime of the 8-GPU run
+    (63 query tiles per scan, rare columns, 250 queries per replaying context)"""
+    from uvaia_amd import hostlib
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, 1000)
+    qn = _names(1000, "query_")
+    refs, _ = gen.generate_bytes(0, 12000)
+    oq = O.Query(qs, qn)
+    gold = O.search(oq, refs, _names(len(refs)), pool=12000, nbest=100, ambig_r=0.5)
+    pq = hostlib.PreparedQuery(qs, qn)
+    with capi.Group(pq, [0, 0, 0, 0], nbest=100, max_pool=4096, piece_refs=1024) as g:
+        g.db_reserve(len(refs))
+        for a in range(0, len(refs), 4000):
+            g.db_append(refs[a:a + 4000])
+        g.reset()
+        g.db_rederive()
+        ent = g.search_resident(12000)
+        n, T, sc, od = g.drain()
+    assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
+    assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+def test_a_group_of_one_is_a_plain_context(data):
+    refs, qs, _ = data
+    q = O.Query(qs, _names(70, "q"))
+    gold = O.search(q, refs, _names(len(refs)), pool=500, nbest=5, ambig_r=1.0)
+    with capi.Group(q, [0], nbest=5, max_pool=500) as g:
+        g.db_reserve(len(refs)); g.db_append(refs)
+        ent = g.search_resident(500)
+        n, T, sc, od = g.drain()
+    assert capi.finalise_heaps(n, sc, od) == _want(gold, q.ntax) and list(T) == gold.final_T
+    assert list(np.nonzero(ent)[0]) == list(gold.saved)

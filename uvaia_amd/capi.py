@@ -21,6 +21,10 @@ SYMBOLS = [
     "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_derived_bytes_per_ref", "uvaia_gpu_scan_variant", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
     "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear", "uvaia_gpu_db_rederive",
     "uvaia_gpu_set_active_queries", "uvaia_gpu_max_tolerance", "uvaia_gpu_search_resident_pool",
+    "uvaia_gpu_db_set_shard", "uvaia_gpu_shard_rows", "uvaia_gpu_shard_scan", "uvaia_gpu_scan_wait", "uvaia_gpu_replay_wait", "uvaia_gpu_set_snapshot", "uvaia_gpu_shard_replay",
+    "uvaia_gpu_group_open", "uvaia_gpu_group_close", "uvaia_gpu_group_last_error", "uvaia_gpu_group_size", "uvaia_gpu_group_member", "uvaia_gpu_group_query_shard",
+    "uvaia_gpu_group_db_reserve", "uvaia_gpu_group_db_append", "uvaia_gpu_group_db_append_packed", "uvaia_gpu_group_db_clear", "uvaia_gpu_group_db_rederive",
+    "uvaia_gpu_group_db_size", "uvaia_gpu_group_reset", "uvaia_gpu_group_search_resident", "uvaia_gpu_group_push", "uvaia_gpu_group_drain", "uvaia_gpu_group_sync",
 ]
 
 
@@ -113,6 +117,30 @@ def load_library():
         "uvaia_gpu_db_side_row_ints": (C.c_int, []),
         "uvaia_gpu_db_export": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_void_p, pi, pi]),
         "uvaia_gpu_db_append_packed": (C.c_int, [vp, C.c_void_p, pi, pi, C.c_int]),
+        "uvaia_gpu_db_set_shard": (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t]),
+        "uvaia_gpu_shard_rows": (C.c_int, [vp]),
+        "uvaia_gpu_shard_scan": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+        "uvaia_gpu_scan_wait": (C.c_int, [vp]),
+        "uvaia_gpu_replay_wait": (C.c_int, [vp]),
+        "uvaia_gpu_set_snapshot": (C.c_int, [vp, C.c_int]),
+        "uvaia_gpu_shard_replay": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64, C.c_int, C.c_int]),
+        "uvaia_gpu_group_open": (C.c_int, [C.POINTER(vp), C.POINTER(_Query), C.c_int, pi, C.c_int, C.c_size_t, C.c_size_t]),
+        "uvaia_gpu_group_close": (None, [vp]),
+        "uvaia_gpu_group_last_error": (C.c_char_p, [vp]),
+        "uvaia_gpu_group_size": (C.c_int, [vp]),
+        "uvaia_gpu_group_member": (vp, [vp, C.c_int]),
+        "uvaia_gpu_group_query_shard": (C.c_int, [vp, C.c_int, pi, pi]),
+        "uvaia_gpu_group_db_reserve": (C.c_int, [vp, C.c_size_t]),
+        "uvaia_gpu_group_db_append": (C.c_int, [vp, pp, pi, C.c_int]),
+        "uvaia_gpu_group_db_append_packed": (C.c_int, [vp, C.c_void_p, pi, pi, C.c_int]),
+        "uvaia_gpu_group_db_clear": (C.c_int, [vp]),
+        "uvaia_gpu_group_db_rederive": (C.c_int, [vp]),
+        "uvaia_gpu_group_db_size": (C.c_size_t, [vp]),
+        "uvaia_gpu_group_reset": (C.c_int, [vp]),
+        "uvaia_gpu_group_search_resident": (C.c_int, [vp, C.c_size_t, C.c_int64, C.POINTER(C.c_uint8)]),
+        "uvaia_gpu_group_push": (C.c_int, [vp, pp, pi, C.c_int, C.c_int64, C.POINTER(C.c_uint8)]),
+        "uvaia_gpu_group_drain": (C.c_int, [vp, pi, pi, pi, C.POINTER(C.c_int64)]),
+        "uvaia_gpu_group_sync": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -246,6 +274,28 @@ class Engine:
     def db_clear(self):
         self._chk(self.L.uvaia_gpu_db_clear(self.ctx))
 
+    # ---- reference shards (several GPUs): see include/uvaia_gpu.h
+    def db_set_shard(self, rank, world, piece_refs):
+        self._chk(self.L.uvaia_gpu_db_set_shard(self.ctx, int(rank), int(world), int(piece_refs)))
+
+    def shard_rows(self):
+        return self.L.uvaia_gpu_shard_rows(self.ctx)
+
+    def shard_scan(self, first, n, cnt_ptr, tmin_ptr):
+        self._chk(self.L.uvaia_gpu_shard_scan(self.ctx, int(first), int(n), C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr)))
+
+    def scan_wait(self):
+        self._chk(self.L.uvaia_gpu_scan_wait(self.ctx))
+
+    def replay_wait(self):
+        self._chk(self.L.uvaia_gpu_replay_wait(self.ctx))
+
+    def set_snapshot(self, v):
+        self._chk(self.L.uvaia_gpu_set_snapshot(self.ctx, int(v)))
+
+    def shard_replay(self, cnt_ptr, tmin_ptr, first, n, ordinal0, q0, q1):
+        self._chk(self.L.uvaia_gpu_shard_replay(self.ctx, C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr), int(first), int(n), int(ordinal0), int(q0), int(q1)))
+
     def db_rederive(self):
         """Rebuild the query-set-dependent planes of the whole resident database (asynchronous)."""
         self._chk(self.L.uvaia_gpu_db_rederive(self.ctx))
@@ -365,3 +415,91 @@ def finalise_heaps(n, scores, ordinals):
         rows.sort(key=lambda r: tuple(-v for v in r[0]))        # list.sort is stable
         out.append(rows)
     return out
+
+
+class Group:
+    """Several contexts driven from one host thread (uvaia_gpu_group_*): the reference-shard search with peer copies as the exchange."""
+
+    def __init__(self, q, devices, nbest=100, max_pool=4096, piece_refs=0):
+        self.L = load_library()
+        self.nq, self.nchar = len(q.seqs), len(q.consensus)
+        self._keep = [_cstrs(q.seqs), q.consensus,
+                      (C.c_size_t * len(q.idx_c))(*[int(x) for x in q.idx_c]),
+                      (C.c_size_t * len(q.idx_m))(*[int(x) for x in q.idx_m]),
+                      (C.c_size_t * len(q.idx))(*[int(x) for x in q.idx])]
+        qq = _Query(self.nq, self.nchar, self._keep[0], q.consensus, self._keep[2], self._keep[3], self._keep[4],
+                    len(q.idx_c), len(q.idx_m), len(q.idx), int(q.trim), int(bool(q.acgt)))
+        self.g = C.c_void_p()
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self.L.uvaia_gpu_group_open(C.byref(self.g), C.byref(qq), int(nbest), dev, len(devices), int(max_pool), int(piece_refs))
+        if rc != 0:
+            msg = self.L.uvaia_gpu_group_last_error(None)
+            self.g = None
+            raise GpuError(rc, msg.decode() if msg else "?")
+        self.slots = self.L.uvaia_gpu_heap_slots(self.L.uvaia_gpu_group_member(self.g, 0))
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.L.uvaia_gpu_group_last_error(self.g)
+            raise GpuError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.uvaia_gpu_group_close(self.g)
+            self.g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def query_shard(self, i):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.L.uvaia_gpu_group_query_shard(self.g, i, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def db_reserve(self, n):
+        self._chk(self.L.uvaia_gpu_group_db_reserve(self.g, int(n)))
+
+    def db_append(self, refs, non_n=None):
+        _k, nn = _int_ptr(non_n)
+        self._chk(self.L.uvaia_gpu_group_db_append(self.g, _cstrs(refs), nn, len(refs)))
+
+    def db_rederive(self):
+        self._chk(self.L.uvaia_gpu_group_db_rederive(self.g))
+
+    def reset(self):
+        self._chk(self.L.uvaia_gpu_group_reset(self.g))
+
+    def sync(self):
+        self._chk(self.L.uvaia_gpu_group_sync(self.g))
+
+    def search_resident(self, pool, ordinal0=0, want_entered=True):
+        ent, p = None, None
+        if want_entered:
+            ent = np.zeros(self.L.uvaia_gpu_group_db_size(self.g), dtype=np.uint8)
+            p = ent.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._chk(self.L.uvaia_gpu_group_search_resident(self.g, int(pool), int(ordinal0), p))
+        return ent
+
+    def push(self, refs, non_n=None, ordinal0=0):
+        entered = np.zeros(len(refs), dtype=np.uint8)
+        _k, nn = _int_ptr(non_n)
+        self._chk(self.L.uvaia_gpu_group_push(self.g, _cstrs(refs), nn, len(refs), int(ordinal0), entered.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return entered
+
+    def drain(self):
+        n = np.zeros(self.nq, dtype=np.int32)
+        T = np.zeros(self.nq, dtype=np.int32)
+        sc = np.zeros((self.nq, self.slots + 1, NSCORE), dtype=np.int32)
+        od = np.zeros((self.nq, self.slots + 1), dtype=np.int64)
+        pi = C.POINTER(C.c_int)
+        self._chk(self.L.uvaia_gpu_group_drain(self.g, n.ctypes.data_as(pi), T.ctypes.data_as(pi), sc.ctypes.data_as(pi), od.ctypes.data_as(C.POINTER(C.c_int64))))
+        return n, T, sc, od

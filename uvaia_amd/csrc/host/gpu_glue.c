@@ -4,8 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-int
-uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int device, size_t max_pool)
+static uvaia_gpu_query
+as_gpu_query (query_t query)
 {
   uvaia_gpu_query q;
   memset (&q, 0, sizeof q);
@@ -17,17 +17,50 @@ uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int dev
   q.n_idx_c = query->n_idx_c; q.n_idx_m = query->n_idx_m; q.n_idx = query->n_idx;
   q.trim = query->trim;
   q.acgt = query->acgt ? 1 : 0;
+  return q;
+}
+
+int
+uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int device, size_t max_pool)
+{
+  uvaia_gpu_query q = as_gpu_query (query);
   return uvaia_gpu_open (ctx, &q, heap_size, device, max_pool);
 }
 
 int
-uvaia_gpu_collect_heaps (uvaia_gpu_ctx *ctx, heap_t *heap, const char *(*name_of) (int64_t, void *), void *user)
+uvaia_gpu_group_open_query (uvaia_gpu_group **group, query_t query, int heap_size, const int *devices, int n_devices, size_t max_pool, size_t piece_refs)
 {
-  const int nq = uvaia_gpu_n_query (ctx), slots = uvaia_gpu_heap_slots (ctx);
+  uvaia_gpu_query q = as_gpu_query (query);
+  return uvaia_gpu_group_open (group, &q, heap_size, devices, n_devices, max_pool, piece_refs);
+}
+
+int
+uvaia_parse_device_list (const char *text, int *devices, int max)
+{
+  int n = 0;
+  const char *p = text;
+  while (*p) {
+    char *end;
+    long a = strtol (p, &end, 10), b;
+    if (end == p || a < 0) return 0;
+    b = a;
+    if (*end == '-') { p = end + 1; b = strtol (p, &end, 10); if (end == p || b < a) return 0; }
+    for (long d = a; d <= b; d++) { if (n == max) return 0; devices[n++] = (int) d; }
+    if (*end == ',') end++; else if (*end) return 0;
+    p = end;
+  }
+  return n;
+}
+
+static int
+collect_heaps (uvaia_gpu_ctx *ctx, uvaia_gpu_group *group, heap_t *heap, const char *(*name_of) (int64_t, void *), void *user)
+{
+  uvaia_gpu_ctx *first = group ? uvaia_gpu_group_member (group, 0) : ctx;
+  const int nq = uvaia_gpu_n_query (first), slots = uvaia_gpu_heap_slots (first);
   int *n = (int *) malloc ((size_t) nq * sizeof (int)), *T = (int *) malloc ((size_t) nq * sizeof (int));
   int *scores = (int *) malloc ((size_t) nq * (slots + 1) * UVAIA_GPU_NSCORE * sizeof (int));
   int64_t *ord = (int64_t *) malloc ((size_t) nq * (slots + 1) * sizeof (int64_t));
-  int rc = (n && T && scores && ord) ? uvaia_gpu_drain (ctx, n, T, scores, ord) : UVAIA_GPU_ENOMEM;
+  int rc = (n && T && scores && ord) ? (group ? uvaia_gpu_group_drain (group, n, T, scores, ord) : uvaia_gpu_drain (ctx, n, T, scores, ord)) : UVAIA_GPU_ENOMEM;
   for (int q = 0; q < nq && !rc; q++) {
     heap_t h = heap[q];
     if (h->heap_size != slots) { rc = UVAIA_GPU_EINVAL; break; }
@@ -44,3 +77,11 @@ uvaia_gpu_collect_heaps (uvaia_gpu_ctx *ctx, heap_t *heap, const char *(*name_of
   free (n); free (T); free (scores); free (ord);
   return rc;
 }
+
+int
+uvaia_gpu_collect_heaps (uvaia_gpu_ctx *ctx, heap_t *heap, const char *(*name_of) (int64_t, void *), void *user)
+{ return collect_heaps (ctx, NULL, heap, name_of, user); }
+
+int
+uvaia_gpu_group_collect_heaps (uvaia_gpu_group *group, heap_t *heap, const char *(*name_of) (int64_t, void *), void *user)
+{ return collect_heaps (NULL, group, heap, name_of, user); }

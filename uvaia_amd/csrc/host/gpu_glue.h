@@ -21,6 +21,12 @@ int uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int
  * heap_insert does, src/min_heap.c:101,112).  Afterwards heap_finalise_heap_qsort() gives the output order. */
 int uvaia_gpu_collect_heaps (uvaia_gpu_ctx *ctx, heap_t *heap, const char *(*name_of) (int64_t ordinal, void *user), void *user);
 
+/* the same two for several GPUs (uvaia_gpu_group_*, include/uvaia_gpu.h): devices[] = HIP devices of the members */
+int uvaia_gpu_group_open_query (uvaia_gpu_group **group, query_t query, int heap_size, const int *devices, int n_devices, size_t max_pool, size_t piece_refs);
+int uvaia_gpu_group_collect_heaps (uvaia_gpu_group *group, heap_t *heap, const char *(*name_of) (int64_t ordinal, void *user), void *user);
+/* "0,2-4" -> {0,2,3,4}; returns the number of devices (0 = syntax error), at most max */
+int uvaia_parse_device_list (const char *text, int *devices, int max);
+
 #ifdef __cplusplus
 }
 #endif

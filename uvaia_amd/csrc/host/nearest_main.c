@@ -14,7 +14,7 @@
 #include "uvdb.h"
 
 typedef struct {
-  int help, version, acgt, keep_resolved, exclude_self, nbest, trim, pool, threads, threads_given, device;
+  int help, version, acgt, keep_resolved, exclude_self, nbest, trim, pool, threads, threads_given, device, devices[64], n_devices;
   double ambig_q, ambig_r;
   const char *out, *query, *packed;
   const char **ref; int n_ref;
@@ -43,6 +43,7 @@ usage (const char *prog, int long_help)
   printf ("  -t, --nthreads=<int>             suggested number of host threads (only sets the default pool size here)\n");
   printf ("  -o, --output=<without suffix>    prefix of xzipped output alignment and table with nearest neighbour sequences\n");
   printf ("  --device=<int>                   GPU to use (default: current device)\n");
+  printf ("  --devices=<list>                 several GPUs, e.g. 0-7 or 0,2,3: every GPU scans its share of the references against all\n                                   queries and keeps the neighbours of its share of the queries (same results as one GPU)\n");
   if (long_help) {
     printf ("\nNeighbours are sorted in the same order as the table columns, using the next column to break ties:\n");
     printf (" 1. ACGT_matches -- considering only ACGT \n 2. text_matches -- exact matches, thus M-M is a match but M-A is not\n");
@@ -66,7 +67,7 @@ parse_options (int argc, char **argv)
     {"keep_resolved", no_argument, 0, 'k'}, {"exclude_self", no_argument, 0, 'x'}, {"nbest", required_argument, 0, 'n'},
     {"trim", required_argument, 0, 1001}, {"query_ambiguity", required_argument, 0, 'a'}, {"ref_ambiguity", required_argument, 0, 'A'},
     {"pool", required_argument, 0, 'p'}, {"reference", required_argument, 0, 'r'}, {"nthreads", required_argument, 0, 't'},
-    {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1002}, {"packed", required_argument, 0, 1003}, {0, 0, 0, 0}};
+    {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1002}, {"packed", required_argument, 0, 1003}, {"devices", required_argument, 0, 1004}, {0, 0, 0, 0}};
   int ch, errors = 0;
   while ((ch = getopt_long (argc, argv, "hvkxn:a:A:p:r:t:o:", longopts, NULL)) != -1) switch (ch) {
     case 'h': o.help = 1; break;
@@ -83,6 +84,7 @@ parse_options (int argc, char **argv)
     case 't': o.threads = atoi (optarg); o.threads_given = 1; break;
     case 'o': o.out = optarg; break;
     case 1002: o.device = atoi (optarg); break;
+    case 1004: o.n_devices = uvaia_parse_device_list (optarg, o.devices, 64); if (!o.n_devices) { fprintf (stderr, "--devices: expected a list such as 0-7 or 0,2,3\n"); exit (EXIT_FAILURE); } break;
     case 1003: o.packed = optarg; break;
     default: errors++;
   }
@@ -166,8 +168,12 @@ main (int argc, char **argv)
   }
 
   /* 2. the engine and the host-side batch */
-  uvaia_gpu_ctx *gpu = NULL;
-  if (uvaia_gpu_open_query (&gpu, query, o.nbest, o.device, (size_t) o.pool)) biomcmc_error ("%s", uvaia_gpu_last_error (NULL));
+  /* one GPU (--device) or several (--devices): a group of one is a plain context */
+  uvaia_gpu_group *grp = NULL;
+  if (!o.n_devices) { o.n_devices = 1; o.devices[0] = o.device; }
+  if (uvaia_gpu_group_open_query (&grp, query, o.nbest, o.devices, o.n_devices, (size_t) (o.n_devices > 1 && o.pool < 64 ? 64 : o.pool), 0)) biomcmc_error ("%s", o.n_devices > 1 ? uvaia_gpu_group_last_error (NULL) : uvaia_gpu_last_error (NULL));
+  uvaia_gpu_ctx *gpu = uvaia_gpu_group_member (grp, 0);
+  if (o.n_devices > 1) fprintf (stderr, "Using %d GPUs: references and queries are shared out among them.\n", o.n_devices);
   char **seq = (char **) biomcmc_malloc ((size_t) o.pool * sizeof (char *)), **name = (char **) biomcmc_malloc ((size_t) o.pool * sizeof (char *));
   int *non_n = (int *) biomcmc_malloc ((size_t) o.pool * sizeof (int));
   uint8_t *entered = (uint8_t *) biomcmc_malloc ((size_t) o.pool);
@@ -198,12 +204,12 @@ main (int argc, char **argv)
       for (uint64_t i = 0; i < n_all; i++) { if (lookup_hashtable (query->aln->taxlabel_hash, (char *) uvdb_name (db, i)) > -1) same_name++; else keep[n++] = i; }
       if (n == n_all) { free (keep); keep = NULL; }
     }
-    if (uvaia_gpu_db_reserve (gpu, (size_t) (n ? n : 1))) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    if (uvaia_gpu_group_db_reserve (grp, (size_t) (n ? n : 1))) biomcmc_error ("%s", uvaia_gpu_group_last_error (grp));
     if (!keep) {
       for (uint64_t t = 0; t < db->h.n_tiles; t += chunk_tiles) {
         const uint64_t nt = (db->h.n_tiles - t < chunk_tiles) ? db->h.n_tiles - t : chunk_tiles;
         const uint64_t first = t * 64, cnt = (first + nt * 64 > n) ? n - first : nt * 64;
-        if (uvaia_gpu_db_append_packed (gpu, uvdb_tile_planes (db, t), db->non_n + first, uvdb_tile_side_rows (db, t), (int) cnt)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+        if (uvaia_gpu_group_db_append_packed (grp, uvdb_tile_planes (db, t), db->non_n + first, uvdb_tile_side_rows (db, t), (int) cnt)) biomcmc_error ("%s", uvaia_gpu_group_last_error (grp));
       }
     } else {
       const size_t tb = (size_t) db->h.tile_bytes, row = (size_t) db->h.side_row_ints, pieces = tb / (64 * 16);   /* 16-byte pieces per lane */
@@ -221,14 +227,14 @@ main (int argc, char **argv)
           nn[k] = db->non_n[r];
           memcpy (side + k * row, uvdb_tile_side_rows (db, r / 64) + (r % 64) * row, row * sizeof (int32_t));
         }
-        if (uvaia_gpu_db_append_packed (gpu, planes, nn, side, (int) cnt)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+        if (uvaia_gpu_group_db_append_packed (grp, planes, nn, side, (int) cnt)) biomcmc_error ("%s", uvaia_gpu_group_last_error (grp));
       }
       free (planes); free (nn); free (side);
     }
     count = (int) n_all;
     fprintf (stderr, "Loaded %d packed sequences from %s in %.3lf secs;\n", (int) n, o.packed, biomcmc_update_elapsed_time (time0));
     uint8_t *ent = (uint8_t *) biomcmc_malloc ((size_t) (n ? n : 1));
-    if (n && uvaia_gpu_search_resident (gpu, (size_t) o.pool, 0, ent)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+    if (n && uvaia_gpu_group_search_resident (grp, (size_t) o.pool, 0, ent)) biomcmc_error ("%s", uvaia_gpu_group_last_error (grp));
     char *text = (char *) biomcmc_malloc ((size_t) query->aln->nchar + 1);
     for (uint64_t i = 0; i < n; i++) if (ent[i]) {     /* dump every sequence that entered some heap, in stream order */
       const uint64_t r = keep ? keep[i] : i;
@@ -263,7 +269,7 @@ main (int argc, char **argv)
         fill++;
       }
       if (fill) {
-        if (uvaia_gpu_push (gpu, (const char *const *) seq, non_n, fill, ordinal, entered)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+        if (uvaia_gpu_group_push (grp, (const char *const *) seq, non_n, fill, ordinal, entered)) biomcmc_error ("%s", uvaia_gpu_group_last_error (grp));
         for (int c = 0; c < fill; c++) if (entered[c]) {   /* dump every sequence that entered some heap, in stream order */
           n_output++;
           write_fasta_record (outstream, name[c], seq[c]);
@@ -273,7 +279,16 @@ main (int argc, char **argv)
         for (int c = 0; c < fill; c++) { free (seq[c]); free (name[c]); }
       }
       if (count >= print_interval && (count % print_interval) < o.pool) {
-        fprintf (stderr, "Total: %d sequences analysed, %d saved, %d poorly resolved. %.3lf secs elapsed. ", count, n_output, n_invalid, biomcmc_update_elapsed_time (time1));
+        int highest = 0;       /* cq->max_incompatible: the largest tolerance over all heaps (src/nearest.c:290-291,323-324) */
+        for (int d = 0; d < o.n_devices; d++) {
+          int v = 0, q0 = 0, q1 = query->aln->ntax;
+          uvaia_gpu_ctx *cx = uvaia_gpu_group_member (grp, d);
+          if (o.n_devices > 1) { uvaia_gpu_group_sync (grp); uvaia_gpu_group_query_shard (grp, d, &q0, &q1); if (q1 <= q0) continue; uvaia_gpu_set_active_queries (cx, q0, q1); }
+          if (!uvaia_gpu_max_tolerance (cx, &v) && v > highest) highest = v;
+          if (o.n_devices > 1) uvaia_gpu_set_active_queries (cx, 0, query->aln->ntax);
+        }
+        fprintf (stderr, "Total: %d sequences analysed, %d saved, %d poorly resolved. Highest number of ACGT mismatches = %d in current neighbourhood. %.3lf secs elapsed. ",
+                 count, n_output, n_invalid, highest, biomcmc_update_elapsed_time (time1));
         if (o.exclude_self) fprintf (stderr, " %d already present in query alignment.\n", same_name); else fprintf (stderr, "\n");
       }
     }
@@ -289,7 +304,7 @@ main (int argc, char **argv)
   /* 3. heaps back to the host, table */
   heap_t *heap = (heap_t *) biomcmc_malloc ((size_t) query->aln->ntax * sizeof (heap_t));
   for (int i = 0; i < query->aln->ntax; i++) heap[i] = new_heap_t (o.nbest);
-  if (uvaia_gpu_collect_heaps (gpu, heap, name_table_get, &names)) biomcmc_error ("%s", uvaia_gpu_last_error (gpu));
+  if (uvaia_gpu_group_collect_heaps (grp, heap, name_table_get, &names)) biomcmc_error ("%s", uvaia_gpu_group_last_error (grp));
   strcpy (outfilename + outlength, ".csv.xz");
   save_distance_table (heap, query, outfilename);
   fprintf (stderr, "Saved distance table to file %s , %.3lf secs elapsed.\n", outfilename, biomcmc_update_elapsed_time (time0));
@@ -297,7 +312,7 @@ main (int argc, char **argv)
   for (int i = 0; i < query->aln->ntax; i++) del_heap_t (heap[i]);
   free (heap); free (seq); free (name); free (non_n); free (entered); free (o.ref);
   name_table_free (&names);
-  uvaia_gpu_close (gpu);
+  uvaia_gpu_group_close (grp);
   del_query_structure (query);
   free (outfilename);
   return EXIT_SUCCESS;

@@ -106,7 +106,9 @@ struct uvaia_gpu_ctx {
   int NR = 0, NR4 = 0, rare_max = -1;   // "rare" columns: all but <= rare_max queries carry the same base; sparse (items), groups follow the dense ones
   uint32_t *d_rmask = nullptr;   // [W4*4] mask of the rare columns
   int *d_split = nullptr;        // derive_all_kernel: w4 range and first gathered bit of each of its four waves
-  bool derive_fused = true;      // UVAIA_GPU_DERIVE_SPLIT=1: the three separate kernels instead (A/B, tests)
+  // reference shards (uvaia_gpu_db_set_shard): the stream is dealt in pieces of shard_pt tiles, piece p belongs to rank p % world; the packed
+  // planes of ALL references are resident (the replay reads them), the planes derived for the query set only for the owned pieces
+  int shard_rank = 0, shard_world = 1; long long shard_pt = 0;
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
@@ -116,7 +118,7 @@ struct uvaia_gpu_ctx {
   int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
-  int scan_parts = 3;            // timing experiments only (UVAIA_GPU_SCAN_PARTS): bit 0 = polymorphic loop, bit 1 = constant/validity loop
+  int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
@@ -171,6 +173,13 @@ int fail(uvaia_gpu_ctx *c, int code, const char *fmt, ...)
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return fail((c), e_ == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// reference shards: does this context keep derived planes for packed tile t, and under which number
+inline bool owns_tile(const uvaia_gpu_ctx *c, long long t) { return c->shard_world == 1 || (t / c->shard_pt) % c->shard_world == c->shard_rank; }
+inline long long dtile_of(const uvaia_gpu_ctx *c, long long t)
+{ return c->shard_world == 1 ? t : (t / (c->shard_pt * c->shard_world)) * c->shard_pt + t % c->shard_pt; }
+inline size_t derived_tiles(const uvaia_gpu_ctx *c, size_t tiles)
+{ return c->shard_world == 1 ? tiles : (size_t)((tiles + (size_t)(c->shard_pt * c->shard_world) - 1) / (size_t)(c->shard_pt * c->shard_world)) * (size_t)c->shard_pt; }
 
 // IUPAC code table: 1..15 = nucleotide set (A=1 C=2 G=4 T=8), 0 = invalid site (N X - ? O .), 0xFF = refused
 void fill_code_table(uint8_t *t)
@@ -269,16 +278,29 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
   if (c->scan_variant == 2) {
     const bool is_db = (tiles == c->d_db);
     const uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
-    const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
+    if (is_db && c->shard_world > 1) {    // the derived planes of an owned piece are numbered densely (uvaia_gpu_db_set_shard)
+      if (!owns_tile(c, tile_first) || tile_first / c->shard_pt != (tile_first + n_tiles - 1) / c->shard_pt)
+        return fail(c, UVAIA_GPU_ESTATE, "tiles %lld..%lld are not inside one piece of this context's reference shard", tile_first, tile_first + n_tiles - 1);
+      tile_first = dtile_of(c, tile_first);
+    }
+    const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
     const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
     // lockstep blocks (4 query tiles x 1 reference tile, 2.4x less traffic): measured faster for 3..16 query tiles once the rebuild of
     // the derived planes shares the memory system with the scan (rank 0 of 8 / 4 query shards: 9.26 -> 8.73, 7.16 -> 7.02 ms per step),
     // even at 32 tiles, slower at 63 (4.86 -> 5.66 ms)
     const int qblock = c->scan_qblock >= 0 ? c->scan_qblock : (nqt3 >= 3 && nqt3 <= 16 ? 1 : 0);
-    dim3 grid3(qblock ? scan_grid_size((nqt3 + 3) / 4, n_tiles) : scan_grid_size(nqt3, (n_tiles + 3) / 4));
-#define SCAN3_LAUNCH(A) hipLaunchKernelGGL((scan3_kernel<16, A>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, c->scan_parts, qt_first, qblock)
-    if (c->acgt) SCAN3_LAUNCH(true); else SCAN3_LAUNCH(false);
+    const int R = c->scan_R;
+    dim3 grid3(qblock ? scan_grid_size((nqt3 + 3) / 4, (n_tiles + R - 1) / R) : scan_grid_size(nqt3, (n_tiles + 4 * R - 1) / (4 * R)));
+#define SCAN3_LAUNCH(A, RR) hipLaunchKernelGGL((scan3_kernel<16, A, RR>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, qt_first, qblock)
+    static const int abl = getenv("UVAIA_GPU_SCAN_ABLATE") ? atoi(getenv("UVAIA_GPU_SCAN_ABLATE")) : 0;     // TEMPORARY experiment: results invalid
+    if (R == 2 && abl && !c->acgt) {
+#define SCAN3_ABL(AB) hipLaunchKernelGGL((scan3_kernel<16, false, 2, AB>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, qt_first, qblock)
+      if (abl == 1) SCAN3_ABL(1); else if (abl == 2) SCAN3_ABL(2); else SCAN3_ABL(3);
+#undef SCAN3_ABL
+    } else
+    if (R == 2) { if (c->acgt) SCAN3_LAUNCH(true, 2); else SCAN3_LAUNCH(false, 2); }
+    else        { if (c->acgt) SCAN3_LAUNCH(true, 1); else SCAN3_LAUNCH(false, 1); }
 #undef SCAN3_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
@@ -365,29 +387,29 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
 }
 
 // planes derived for the open query set (column-compressed scan) for the whole tiles that hold slots slot0 .. slot0 + n_ref - 1
+// (resident database with reference shards: only the tiles of the pieces this context owns)
 int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipStream_t st = nullptr, bool v_in_place = false)
 {
   if (!st) st = c->stream;
-  if (c->fullscan || c->scan_variant != 2 || n_ref <= 0) return 0;     // only the column-compressed scan reads derived planes
+  if (c->fullscan || c->scan_variant != 2 || n_ref <= 0 || !c->d_split) return 0;     // only the column-compressed scan reads derived planes
   const bool is_db = (tiles == c->d_db);
   uint4 *ev = is_db ? c->d_db_ev : c->d_batch_ev, *poly = is_db ? c->d_db_poly : c->d_batch_poly;
   int *tote = is_db ? c->d_db_tote : c->d_batch_tote;
   uint32_t *grp = is_db ? c->d_db_grp : c->d_batch_grp;
   const long long t0 = slot0 / 64, t1 = (slot0 + n_ref - 1) / 64;
-  const int nblk = (int)(t1 - t0 + 1);
-  if (c->derive_fused && c->d_split) {
-#define DERIVE_ALL(A, V) hipLaunchKernelGGL((derive_all_kernel<A, V>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly)
-    if (c->acgt) { if (v_in_place) DERIVE_ALL(true, false); else DERIVE_ALL(true, true); }
-    else         { if (v_in_place) DERIVE_ALL(false, false); else DERIVE_ALL(false, true); }
+  const bool sharded = is_db && c->shard_world > 1;
+  for (long long a = t0; a <= t1;) {
+    // [a, b]: the whole range, or its part inside one piece of the shard map
+    const long long b = sharded ? std::min(t1, (a / c->shard_pt + 1) * c->shard_pt - 1) : t1;
+    if (!sharded || owns_tile(c, a)) {
+      const int nblk = (int)(b - a + 1);
+      const long long dt = sharded ? dtile_of(c, a) : a;
+#define DERIVE_ALL(A, V) hipLaunchKernelGGL((derive_all_kernel<A, V>), dim3(nblk), dim3(256), 0, st, tiles, a, dt, c->W4, c->d_cls, c->d_rmask, c->d_split, c->NP4, c->NR4, ev, tote, grp, poly)
+      if (c->acgt) { if (v_in_place) DERIVE_ALL(true, false); else DERIVE_ALL(true, true); }
+      else         { if (v_in_place) DERIVE_ALL(false, false); else DERIVE_ALL(false, true); }
 #undef DERIVE_ALL
-  } else if (c->acgt) {
-    hipLaunchKernelGGL((derive_ev_kernel<true>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
-    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<true>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
-  } else {
-    hipLaunchKernelGGL((derive_ev_kernel<false>), dim3(nblk), dim3(256), 0, st, tiles, t0, c->W4, c->d_cls, ev, tote, grp);
-    if (c->NP4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, 0, c->d_cls + 3, 4, poly);
-    if (c->NR4) hipLaunchKernelGGL((gather_poly_kernel<false>), dim3(nblk), dim3(64), 0, st, tiles, t0, c->W4, c->NP4 + c->NR4, c->NP4, c->d_rmask, 1, poly);
+    }
+    a = b + 1;
   }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -672,7 +694,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         for (int t = 0; t < c->nq_pad / 16; t++) { u |= flg[((size_t)t * c->W4 + g) * 2]; uy |= flg[((size_t)t * c->W4 + g) * 2 + 1]; }
         c->need_e_groups += (u & 0xFFFFu) != 0; c->need_v_groups += (u >> 16) != 0; c->need_g_groups += uy != 0;
       }
-      { const char *ep = getenv("UVAIA_GPU_SCAN_PARTS"); if (ep) c->scan_parts = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_REPLAY_PRIO"); if (ep) c->replay_prio = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_SCAN_LDS_PAD"); if (ep) c->scan_lds_pad = atoi(ep); }
       { const char *ep = getenv("UVAIA_GPU_REPLAY_LQ"); if (ep) c->replay_lq = atoi(ep); }
@@ -694,16 +715,17 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           split[5 + v] = nd; split[10 + v] = nr;
         }
         OPENCHK(hipMalloc(&c->d_split, sizeof split)); OPENCHK(hipMemcpy(c->d_split, split, sizeof split, hipMemcpyHostToDevice));
-        c->derive_fused = getenv("UVAIA_GPU_DERIVE_SPLIT") == nullptr;
       }
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
-      std::vector<uint32_t> strm, sdir((size_t)(c->nq_pad / 16) * 2, 0u);
+      { const char *er = getenv("UVAIA_GPU_SCAN_R"); if (er) c->scan_R = atoi(er) == 1 ? 1 : 2; }
+      const uint32_t row_b = 256u * (uint32_t)c->scan_R;      // bytes of a query's counter row in a wave's LDS block: 64 lanes x R tiles x 4
+      struct TileStream { std::vector<uint32_t> u; uint32_t nrec = 0, nrare = 0; };
+      const int n_qt = c->nq_pad / 16;
+      std::vector<TileStream> ts((size_t)n_qt);
       std::vector<uint8_t> rare_groups_needed((size_t)std::max(c->NR4, 1), 0);
-      for (int t = 0; t < c->nq_pad / 16; t++) {
-        sdir[(size_t)t * 2] = (uint32_t)strm.size();
-        uint32_t nrec = 0;
-        size_t prev_hdr = (size_t)-1;
+      parallel_for(n_qt, [&](int t) {
+        std::vector<uint32_t> &strm = ts[(size_t)t].u;
         for (int g = 0; g < c->W4; g++) {
           const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
           if ((fx | fy) == 0u) continue;
@@ -721,32 +743,30 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           uint32_t nw[4] = {0, 0, 0, 0};                // word items per word of the group, listed word by word
           auto word_of = [&](int q) { const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8; int j = 0; while (!(src[j] | src[4 + j])) j++; return j; };
           for (uint32_t m = f1; m; m &= m - 1) nw[word_of(__builtin_ctz(m))]++;
-          const uint32_t hw0 = (uint32_t)g * 2048u | ((fx & 0xFFFFu) ? 1u : 0u) | ((fx >> 16) ? 2u : 0u) | (fy ? 4u : 0u);
-          prev_hdr = strm.size();
-          strm.push_back(hw0);
+          const size_t hdr = strm.size();
+          strm.push_back((uint32_t)g * 2048u);
           strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u | nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19);
           strm.push_back((uint32_t)__builtin_popcount(f4)); strm.push_back(0u);
-          for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * 256u);
-          while (strm.size() & 3) strm.push_back(16u * 256u);                                  // scratch row
+          for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * row_b);
+          while (strm.size() & 3) strm.push_back(16u * row_b);                                  // scratch row
           for (uint32_t m = f4; m; m &= m - 1) {
             const int q = __builtin_ctz(m);
             const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
             strm.insert(strm.end(), src, src + 8);
-            strm.push_back((uint32_t)q * 256u); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
+            strm.push_back((uint32_t)q * row_b); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
           }
           for (int j = 0; j < 4; j++)
             for (uint32_t m = f1; m; m &= m - 1) {
               const int q = __builtin_ctz(m);
               if (word_of(q) != j) continue;
               const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
-              strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)q * 256u); strm.push_back(0u);
+              strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)q * row_b); strm.push_back(0u);
             }
-          strm[prev_hdr + 3] = (uint32_t)(strm.size() - prev_hdr);
-          nrec++;
+          strm[hdr + 3] = (uint32_t)(strm.size() - hdr);
+          ts[(size_t)t].nrec++;
         }
         // rare records: { byte offset of the rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }
         // + items { sites, their lo bits, their hi bits, LDS offset } listed word by word
-        uint32_t nrare = 0;
         for (int r4 = 0; r4 < c->NR4; r4++) {
           uint32_t nw[4] = {0, 0, 0, 0};
           for (int q = 0; q < 16; q++) for (const RareWord &rw : rare_q[(size_t)t * 16 + q]) if ((rw.word >> 2) == r4) nw[rw.word & 3]++;
@@ -754,14 +774,22 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           strm.push_back((uint32_t)(c->NP4 + r4) * 3072u); strm.push_back(nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19); strm.push_back(0u); strm.push_back(0u);
           for (int j = 0; j < 4; j++)
             for (int q = 0; q < 16; q++) for (const RareWord &rw : rare_q[(size_t)t * 16 + q]) if (rw.word == r4 * 4 + j) {
-              strm.push_back(rw.m); strm.push_back(rw.l); strm.push_back(rw.h); strm.push_back((uint32_t)q * 256u);
+              strm.push_back(rw.m); strm.push_back(rw.l); strm.push_back(rw.h); strm.push_back((uint32_t)q * row_b);
             }
-          nrare++; rare_groups_needed[(size_t)r4] = 1;
+          ts[(size_t)t].nrare++; rare_groups_needed[(size_t)r4] = 1;     // (a byte set to 1 by several threads)
         }
-        sdir[(size_t)t * 2 + 1] = nrec | (nrare << 16);
+      });
+      std::vector<uint32_t> strm, sdir((size_t)n_qt * 2, 0u);
+      for (int t = 0; t < n_qt; t++) {
+        sdir[(size_t)t * 2] = (uint32_t)strm.size();
+        sdir[(size_t)t * 2 + 1] = ts[(size_t)t].nrec | (ts[(size_t)t].nrare << 16);
+        strm.insert(strm.end(), ts[(size_t)t].u.begin(), ts[(size_t)t].u.end());
+        // the header walk runs two records ahead and takes the length of a record from its header: a tile's records are followed by a
+        // zero header of length 4 (rare records hold no length), so that the look-ahead stays inside the stream
+        strm.push_back(0u); strm.push_back(0u); strm.push_back(0u); strm.push_back(4u);
       }
       for (uint8_t u : rare_groups_needed) c->need_r_groups += u;
-      strm.resize(strm.size() + 64, 0u);                                // the kernel prefetches one item past the end
+      strm.resize(strm.size() + 64, 0u);                                // the kernel prefetches items and headers past the end
       OPENCHK(hipMalloc(&c->d_stream, strm.size() * 4)); OPENCHK(hipMemcpy(c->d_stream, strm.data(), strm.size() * 4, hipMemcpyHostToDevice));
       OPENCHK(hipMalloc(&c->d_sdir, sdir.size() * 4)); OPENCHK(hipMemcpy(c->d_sdir, sdir.data(), sdir.size() * 4, hipMemcpyHostToDevice));
     }
@@ -946,10 +974,11 @@ int uvaia_gpu_db_reserve(uvaia_gpu_ctx *c, size_t cap)
   HIPCHK(c, hipMemset(c->d_db, 0, tiles * tile_u4 * sizeof(uint4)));
   HIPCHK(c, hipMalloc(&c->d_db_nonn, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_nonn, 0, tiles * 64 * sizeof(int)));
-  HIPCHK(c, hipMalloc(&c->d_db_ev, tiles * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
-  HIPCHK(c, hipMalloc(&c->d_db_grp, tiles * (size_t)c->W4 * 64 * sizeof(uint32_t)));
-  HIPCHK(c, hipMalloc(&c->d_db_poly, tiles * (size_t)std::max(c->NP4 + c->NR4, 1) * 3 * 64 * sizeof(uint4)));
-  HIPCHK(c, hipMalloc(&c->d_db_tote, tiles * 64 * sizeof(int)));
+  const size_t dtiles = derived_tiles(c, tiles);      // reference shards: derived planes for the owned pieces only
+  HIPCHK(c, hipMalloc(&c->d_db_ev, dtiles * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_grp, dtiles * (size_t)c->W4 * 64 * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&c->d_db_poly, dtiles * (size_t)std::max(c->NP4 + c->NR4, 1) * 3 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_db_tote, dtiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_tot, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMemset(c->d_db_tot, 0, tiles * 64 * sizeof(int)));
   HIPCHK(c, hipMalloc(&c->d_db_amb, tiles * 64 * AMB_ROW * sizeof(int)));
@@ -1115,7 +1144,6 @@ int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
     }
   }
   std::vector<SubSlice> plan = plan_subslices(c, 0, c->db_n, c->max_pool);
-  if (getenv("UVAIA_GPU_DERIVE_ONE_LAUNCH")) plan.assign(1, SubSlice{0, c->db_n, true});
   size_t k = 0;
   long long t_done = 0;                 // slices that are not tile aligned share a tile: it belongs to the earlier chunk
   for (const SubSlice &sl : plan) {
@@ -1127,7 +1155,7 @@ int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
       HIPCHK(c, hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
       c->derive_chunks.push_back(d);
     }
-    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), c->derive_stream, c->derive_fused && getenv("UVAIA_GPU_DERIVE_REWRITE_V") == nullptr); if (rc) return rc;
+    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), c->derive_stream, true); if (rc) return rc;
     c->derive_chunks[k].t0 = t0; c->derive_chunks[k].t1 = t1;
     HIPCHK(c, hipEventRecord(c->derive_chunks[k].done, c->derive_stream));
     k++;
@@ -1370,7 +1398,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
-                                  c->scan_variant == 2 ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
+                                  (c->scan_variant == 2 && c->shard_world == 1) ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1390,7 +1418,8 @@ int uvaia_gpu_set_active_queries(uvaia_gpu_ctx *c, int q0, int q1)
 {
   if (!c) return UVAIA_GPU_EINVAL;
   if (q0 < 0 || q1 > c->nq || q1 <= q0 || (q0 % 16)) return fail(c, UVAIA_GPU_EINVAL, "active queries [%d,%d): need 0 <= q0 < q1 <= %d and q0 a multiple of 16", q0, q1, c->nq);
-  if (c->fullscan || c->scan_variant != 2) { if (q0 != 0 || q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "query shards need the default scan"); }
+  // (with reference shards the range only selects whose tolerances uvaia_gpu_max_tolerance looks at: every scan covers all queries)
+  if ((c->fullscan || c->scan_variant != 2) && c->shard_world == 1) { if (q0 != 0 || q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "query shards need the default scan"); }
   c->act_q0 = q0; c->act_q1 = q1;
   return 0;
 }
@@ -1415,6 +1444,352 @@ int uvaia_gpu_entered_flags(uvaia_gpu_ctx *c, uint8_t *out, int clear)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (out && c->db_n) HIPCHK(c, hipMemcpy(out, c->d_entered, c->db_n, hipMemcpyDeviceToHost));
   if (clear && c->db_n) HIPCHK(c, hipMemset(c->d_entered, 0, ((c->db_n + 63) / 64) * 64));
+  return 0;
+}
+
+// ---- reference shards (several GPUs; DESIGN.md "Multi-GPU").  Every context holds the packed planes of ALL references (what the
+// replay's on-demand counters read; query-independent, loaded once) but derives and scans only its share: the stream is dealt in
+// pieces of piece_refs references (whole tiles), piece p belongs to rank p % world.  A rank scans a piece against ALL queries into
+// caller-owned buffers, the caller moves the rows of each query shard to the rank that replays those queries (RCCL all-to-all
+// between processes, peer copies inside one: uvaia_gpu_group_*), and every rank replays its queries over the pieces in stream order.
+int uvaia_gpu_db_set_shard(uvaia_gpu_ctx *c, int rank, int world, size_t piece_refs)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, UVAIA_GPU_EINVAL, "rank %d of %d", rank, world);
+  if (world > 1 && (piece_refs < 64 || piece_refs % 64 || piece_refs > c->max_pool)) return fail(c, UVAIA_GPU_EINVAL, "a piece holds a whole number of tiles of 64 references, at most max_pool = %zu (got %zu)", c->max_pool, piece_refs);
+  if (c->d_db || c->db_n) return fail(c, UVAIA_GPU_ESTATE, "the reference shard is set before the database is reserved");
+  if (world > 1 && c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "reference shards need the two-counter scans (alignments up to 49 000 columns)");
+  c->shard_rank = rank; c->shard_world = world; c->shard_pt = world > 1 ? (long long)(piece_refs / 64) : 0;
+  return 0;
+}
+
+int uvaia_gpu_shard_rows(const uvaia_gpu_ctx *c) { return c ? c->nq_pad : 0; }
+
+// Pair counters of the references [first, first + n) (inside one piece of this context's shard) against ALL queries:
+//   cnt  [uvaia_gpu_shard_rows()][tiles * 64] int2,  tmin [uvaia_gpu_shard_rows()][tiles] int2,  tiles = the tiles the range touches;
+// a reference sits in column (its position - 64 * (first / 64)).  Asynchronous; uvaia_gpu_scan_wait() waits for the scans issued so far.
+int uvaia_gpu_shard_scan(uvaia_gpu_ctx *c, size_t first, size_t n, void *cnt, void *tmin)
+{
+  if (!c || !cnt || !tmin) return c ? fail(c, UVAIA_GPU_EINVAL, "NULL buffer") : UVAIA_GPU_EINVAL;
+  if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "reference shards need the two-counter scans");
+  if (n < 1 || first + n > c->db_n) return fail(c, UVAIA_GPU_EINVAL, "range [%zu,+%zu) outside the database", first, n);
+  const long long tf = (long long)(first / 64);
+  const int n_tiles = (int)((first + n + 63) / 64 - first / 64);
+  if ((size_t)n_tiles * 64 > c->pool_pad) return fail(c, UVAIA_GPU_EINVAL, "range of %zu references above max_pool %zu", n, c->max_pool);
+  hipStream_t ss = c->scan_streams[0];
+  for (size_t k = 0; k < c->derive_pending; k++) {
+    const auto &d = c->derive_chunks[k];
+    if (d.t0 < tf + n_tiles && d.t1 > tf) HIPCHK(c, hipStreamWaitEvent(ss, d.done, 0));
+  }
+  const int rb = (int)(first - (size_t)tf * 64);
+  const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
+  return launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, (int2 *)cnt, n_tiles * 64, bytes, ss, (int2 *)tmin, rb, rb + (int)n, c->d_mp[0]);
+}
+
+int uvaia_gpu_scan_wait(uvaia_gpu_ctx *c)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
+  return 0;
+}
+
+// waits for the replays issued so far (their counter buffers may then be overwritten); scans keep running
+int uvaia_gpu_replay_wait(uvaia_gpu_ctx *c)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// cq->max_incompatible of the batch that starts now (src/nearest.c:290-291), given by the caller: the maximum over the ranks of
+// uvaia_gpu_max_tolerance().  Only matters when the query set has constant-and-complete columns.
+int uvaia_gpu_set_snapshot(uvaia_gpu_ctx *c, int snapshot)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(c->d_snap, &snapshot, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Gate + heaps of queries [q0, q1) over references [first, first + n) of the resident database, from counters laid out as
+// uvaia_gpu_shard_scan writes them but holding the rows of queries q0 .. q1-1 only (row 0 = query q0).  Asynchronous on the
+// replay stream; the buffers must stay valid and complete until uvaia_gpu_sync().
+int uvaia_gpu_shard_replay(uvaia_gpu_ctx *c, const void *cnt, const void *tmin, size_t first, size_t n, int64_t ordinal0, int q0, int q1)
+{
+  if (!c || !cnt || !tmin) return c ? fail(c, UVAIA_GPU_EINVAL, "NULL buffer") : UVAIA_GPU_EINVAL;
+  if (c->fullscan) return fail(c, UVAIA_GPU_ESTATE, "reference shards need the two-counter scans");
+  if (q0 < 0 || q1 > c->nq || q1 < q0) return fail(c, UVAIA_GPU_EINVAL, "bad query range [%d,%d)", q0, q1);
+  if (first + n > c->db_n) return fail(c, UVAIA_GPU_EINVAL, "range [%zu,+%zu) outside the database", first, n);
+  if (n < 1 || q1 == q0) return 0;
+  const long long tf = (long long)(first / 64);
+  const int n_tiles = (int)((first + n + 63) / 64 - first / 64), ppad = n_tiles * 64;
+  if ((size_t)ppad > c->pool_pad) return fail(c, UVAIA_GPU_EINVAL, "range of %zu references above max_pool %zu", n, c->max_pool);
+  const int rb = (int)(first - (size_t)tf * 64), re = rb + (int)n;
+  if (c->n_idx_c > 0) {
+    if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+    else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  }
+  const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
+  const int lq_words = (c->replay_lq && !c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
+  // the kernel indexes rows by query number: shift the bases so that row q0 is the buffer's first row
+  const int2 *cntp = (const int2 *)cnt - (ptrdiff_t)q0 * ppad, *tminp = (const int2 *)tmin - (ptrdiff_t)q0 * (ppad / 64);
+  const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
+  uint8_t *ent = c->d_entered + tf * 64;
+  // --acgt: dist_unique of the pairs that reach a heap is counted from the packed planes (the scan's per-pair count stays on the scanning rank)
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cntp, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, tminp, (const int *)nullptr, lq_words, c->replay_prio, \
+                                  (const uint4 *)nullptr, c->NP4 + c->NR4, c->NP4, 0, (const uint32_t *)nullptr)
+  if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
+  else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
+#undef REPLAY2
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- a group of contexts in ONE process (the C command line's --devices): the reference-shard protocol above with peer copies as
+// the exchange.  Replaces the batch loop of src/nearest.c:245-330 for several GPUs.  One host thread drives all devices: every
+// step is an asynchronous launch or copy, ordered by events across the devices' streams.
+struct uvaia_gpu_group {
+  int n = 0, nq = 0, rows = 0, cons = 0;
+  size_t piece = 0;
+  std::vector<uvaia_gpu_ctx *> ctx;
+  std::vector<int> q0, q1;                      // query shard of each member (multiples of 16)
+  struct Member {
+    int2 *send_cnt[2] = {}, *send_tmin[2] = {}, *recv_cnt[2] = {}, *recv_tmin[2] = {};
+    hipStream_t copy = nullptr;
+    hipEvent_t scanned[2] = {}, fetched[2] = {}, replayed[2] = {};    // scan into send[b] done; this member's copies out of everyone's send[b] done; replays from recv[b] done
+    bool fetched_rec[2] = {}, replayed_rec[2] = {};
+  };
+  std::vector<Member> m;
+  std::string err;
+};
+
+static int gfail(uvaia_gpu_group *g, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (g) g->err = buf; else g_open_error = buf;
+  return code;
+}
+#define GCHK(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return gfail((g), UVAIA_GPU_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define GCTX(g, i, call) do { int rc_ = (call); if (rc_) return gfail((g), rc_, "device %d: %s", (g)->ctx[(size_t)(i)]->device, uvaia_gpu_last_error((g)->ctx[(size_t)(i)])); } while (0)
+
+const char *uvaia_gpu_group_last_error(const uvaia_gpu_group *g) { return g ? g->err.c_str() : g_open_error.c_str(); }
+int uvaia_gpu_group_size(const uvaia_gpu_group *g) { return g ? g->n : 0; }
+uvaia_gpu_ctx *uvaia_gpu_group_member(uvaia_gpu_group *g, int i) { return (g && i >= 0 && i < g->n) ? g->ctx[(size_t)i] : nullptr; }
+
+void uvaia_gpu_group_close(uvaia_gpu_group *g)
+{
+  if (!g) return;
+  for (int i = 0; i < (int)g->ctx.size(); i++) {
+    if (!g->ctx[(size_t)i]) continue;
+    hipSetDevice(g->ctx[(size_t)i]->device);
+    uvaia_gpu_sync(g->ctx[(size_t)i]);
+    if (i < (int)g->m.size()) {
+      auto &mm = g->m[(size_t)i];
+      if (mm.copy) { hipStreamSynchronize(mm.copy); hipStreamDestroy(mm.copy); }
+      for (int b = 0; b < 2; b++) {
+        void *p[] = {mm.send_cnt[b], mm.send_tmin[b], mm.recv_cnt[b], mm.recv_tmin[b]};
+        for (void *x : p) if (x) hipFree(x);
+        hipEvent_t ev[] = {mm.scanned[b], mm.fetched[b], mm.replayed[b]};
+        for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+      }
+    }
+    uvaia_gpu_close(g->ctx[(size_t)i]);
+  }
+  delete g;
+}
+
+// devices[i]: HIP device of member i (a device may be listed more than once: several contexts on one GPU).  piece_refs: references per
+// piece of the shard map (multiple of 64, at most max_pool); 0 = max_pool rounded down to whole tiles, at most 8 192.
+int uvaia_gpu_group_open(uvaia_gpu_group **out, const uvaia_gpu_query *q, int heap_size, const int *devices, int n_devices, size_t max_pool, size_t piece_refs)
+{
+  if (!out) return gfail(nullptr, UVAIA_GPU_EINVAL, "group is NULL");
+  *out = nullptr;
+  if (!devices || n_devices < 1 || n_devices > 64) return gfail(nullptr, UVAIA_GPU_EINVAL, "1 to 64 devices");
+  if (max_pool < 64 && n_devices > 1) return gfail(nullptr, UVAIA_GPU_EINVAL, "several devices need max_pool >= 64");
+  uvaia_gpu_group *g = new uvaia_gpu_group();
+  g->n = n_devices;
+  g->piece = n_devices == 1 ? 0 : (piece_refs ? piece_refs : std::min<size_t>(8192, max_pool / 64 * 64));
+  if (g->n > 1 && (g->piece < 64 || g->piece % 64 || g->piece > max_pool)) { delete g; return gfail(nullptr, UVAIA_GPU_EINVAL, "piece of %zu references: need a multiple of 64 up to max_pool", piece_refs); }
+  g->ctx.assign((size_t)g->n, nullptr);
+  for (int i = 0; i < g->n; i++) {
+    int rc = uvaia_gpu_open(&g->ctx[(size_t)i], q, heap_size, devices[i], max_pool);
+    if (rc) { uvaia_gpu_group_close(g); return rc; }                      // message already in the open error
+    rc = uvaia_gpu_db_set_shard(g->ctx[(size_t)i], i, g->n, g->piece);
+    if (rc) { gfail(nullptr, rc, "%s", uvaia_gpu_last_error(g->ctx[(size_t)i])); uvaia_gpu_group_close(g); return rc; }
+  }
+  g->nq = q->n_query; g->rows = g->ctx[0]->nq_pad; g->cons = q->n_idx_c > 0;
+  {   // contiguous query shards, whole query tiles
+    int per = (g->nq + g->n - 1) / g->n; per = (per + 15) / 16 * 16;
+    for (int i = 0; i < g->n; i++) { const int a = std::min(g->nq, i * per); g->q0.push_back(a); g->q1.push_back(std::min(g->nq, a + per)); }
+  }
+  g->m.resize((size_t)g->n);
+  if (g->n > 1) {
+    const size_t pcols = g->piece + 64;                      // a range that starts inside a tile touches one tile more
+    for (int i = 0; i < g->n; i++) {
+      auto &mm = g->m[(size_t)i];
+      const size_t myrows = (size_t)std::max(1, g->q1[(size_t)i] - g->q0[(size_t)i]);
+      hipError_t e = hipSetDevice(g->ctx[(size_t)i]->device);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&mm.copy, hipStreamNonBlocking);
+      for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc(&mm.send_cnt[b], (size_t)g->rows * pcols * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc(&mm.send_tmin[b], (size_t)g->rows * (pcols / 64) * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc(&mm.recv_cnt[b], (size_t)g->n * myrows * pcols * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc(&mm.recv_tmin[b], (size_t)g->n * myrows * (pcols / 64) * sizeof(int2));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&mm.scanned[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&mm.fetched[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&mm.replayed[b], hipEventDisableTiming);
+      }
+      if (e != hipSuccess) { const int code = gfail(nullptr, e == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "group buffers on device %d: %s", devices[i], hipGetErrorString(e)); uvaia_gpu_group_close(g); return code; }
+      for (int j = 0; j < g->n; j++) if (devices[j] != devices[i]) { int can = 0; if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) { hipError_t pe = hipDeviceEnablePeerAccess(devices[j], 0); if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(); } }
+    }
+  }
+  *out = g;
+  return 0;
+}
+
+int uvaia_gpu_group_query_shard(const uvaia_gpu_group *g, int i, int *q0, int *q1)
+{ if (!g || i < 0 || i >= g->n || !q0 || !q1) return UVAIA_GPU_EINVAL; *q0 = g->q0[(size_t)i]; *q1 = g->q1[(size_t)i]; return 0; }
+
+#define EACH_MEMBER(g, expr) do { for (int i_ = 0; i_ < (g)->n; i_++) { GCHK(g, hipSetDevice((g)->ctx[(size_t)i_]->device)); uvaia_gpu_ctx *cx = (g)->ctx[(size_t)i_]; GCTX(g, i_, (expr)); } } while (0)
+int uvaia_gpu_group_db_reserve(uvaia_gpu_group *g, size_t cap) { if (!g) return UVAIA_GPU_EINVAL; EACH_MEMBER(g, uvaia_gpu_db_reserve(cx, cap)); return 0; }
+int uvaia_gpu_group_db_clear(uvaia_gpu_group *g) { if (!g) return UVAIA_GPU_EINVAL; EACH_MEMBER(g, uvaia_gpu_db_clear(cx)); return 0; }
+int uvaia_gpu_group_reset(uvaia_gpu_group *g) { if (!g) return UVAIA_GPU_EINVAL; EACH_MEMBER(g, uvaia_gpu_reset(cx)); return 0; }
+int uvaia_gpu_group_sync(uvaia_gpu_group *g)
+{
+  if (!g) return UVAIA_GPU_EINVAL;
+  for (int i = 0; i < g->n; i++) { GCHK(g, hipSetDevice(g->ctx[(size_t)i]->device)); if (g->m[(size_t)i].copy) GCHK(g, hipStreamSynchronize(g->m[(size_t)i].copy)); GCTX(g, i, uvaia_gpu_sync(g->ctx[(size_t)i])); }
+  return 0;
+}
+// every member receives the packed planes of every reference (the replay reads them); each derives the planes of its own pieces
+int uvaia_gpu_group_db_append(uvaia_gpu_group *g, const char *const *seq, const int *non_n, int n_ref) { if (!g) return UVAIA_GPU_EINVAL; EACH_MEMBER(g, uvaia_gpu_db_append(cx, seq, non_n, n_ref)); return 0; }
+int uvaia_gpu_group_db_append_packed(uvaia_gpu_group *g, const void *planes, const int *non_n, const int *side_rows, int n_ref)
+{ if (!g) return UVAIA_GPU_EINVAL; EACH_MEMBER(g, uvaia_gpu_db_append_packed(cx, planes, non_n, side_rows, n_ref)); return 0; }
+int uvaia_gpu_group_db_rederive(uvaia_gpu_group *g) { if (!g) return UVAIA_GPU_EINVAL; EACH_MEMBER(g, uvaia_gpu_db_rederive(cx)); return 0; }
+size_t uvaia_gpu_group_db_size(const uvaia_gpu_group *g) { return g ? uvaia_gpu_db_size(g->ctx[0]) : 0; }
+#undef EACH_MEMBER
+
+// The whole while-loop of src/nearest.c:249-330 over the resident database in batches of `pool` references, sharded: per batch
+// the snapshot of the tolerances is the maximum over ALL members' heaps (src/nearest.c:290-291; only taken when the query set has
+// constant-and-complete columns, otherwise batches have no effect); the pieces of the shard map inside the batch are scanned by
+// their owners, `n` pieces (one per member) at a time, the rows of every query shard are copied to the member that replays them,
+// and each member replays its queries over the pieces in stream order.  Asynchronous unless entered != NULL.
+int uvaia_gpu_group_search_resident(uvaia_gpu_group *g, size_t pool, int64_t ordinal0, uint8_t *entered)
+{
+  if (!g) return UVAIA_GPU_EINVAL;
+  const size_t total = uvaia_gpu_db_size(g->ctx[0]);
+  if (g->n == 1) {
+    GCHK(g, hipSetDevice(g->ctx[0]->device));
+    GCTX(g, 0, uvaia_gpu_search_resident(g->ctx[0], pool, ordinal0, entered));
+    return 0;
+  }
+  if (pool < 1) return gfail(g, UVAIA_GPU_EINVAL, "pool must be positive");
+  for (int i = 0; i < g->n; i++) {
+    if (uvaia_gpu_db_size(g->ctx[(size_t)i]) != total) return gfail(g, UVAIA_GPU_ESTATE, "members hold different databases");
+    GCHK(g, hipSetDevice(g->ctx[(size_t)i]->device));
+    GCHK(g, hipMemsetAsync(g->ctx[(size_t)i]->d_entered, 0, ((total + 63) / 64) * 64, g->ctx[(size_t)i]->stream));
+  }
+  if (!total) return 0;
+  if (!g->cons) pool = total;                          // batches act through the snapshot only (see plan_subslices)
+  struct Piece { size_t first, n; int owner; };
+  unsigned stripe_no = 0;
+  for (size_t a = 0; a < total; a += pool) {
+    const size_t b = std::min(total, a + pool);
+    if (g->cons) {   // the batch snapshot: needs every member's tolerances as the previous batch left them
+      int snap = -0x7fffffff;
+      for (int i = 0; i < g->n; i++) { GCHK(g, hipSetDevice(g->ctx[(size_t)i]->device)); uvaia_gpu_ctx *cx = g->ctx[(size_t)i]; const int a0 = cx->act_q0, a1 = cx->act_q1;
+        if (g->q1[(size_t)i] > g->q0[(size_t)i]) { cx->act_q0 = g->q0[(size_t)i]; cx->act_q1 = g->q1[(size_t)i]; int v = 0; const int rc = uvaia_gpu_max_tolerance(cx, &v); cx->act_q0 = a0; cx->act_q1 = a1; GCTX(g, i, rc); snap = std::max(snap, v); } }
+      for (int i = 0; i < g->n; i++) { GCHK(g, hipSetDevice(g->ctx[(size_t)i]->device)); GCTX(g, i, uvaia_gpu_set_snapshot(g->ctx[(size_t)i], snap)); }
+    }
+    std::vector<Piece> pieces;                          // the parts of the shard map's pieces inside [a, b), in stream order
+    for (size_t x = a; x < b;) { const size_t pe = std::min(b, (x / g->piece + 1) * g->piece); pieces.push_back({x, pe - x, (int)((x / g->piece) % (size_t)g->n)}); x = pe; }
+    for (size_t s0 = 0; s0 < pieces.size(); s0 += (size_t)g->n, stripe_no++) {
+      const size_t s1 = std::min(pieces.size(), s0 + (size_t)g->n);
+      const int bsel = (int)(stripe_no & 1u);
+      // 1. scans, each on its owner (consecutive pieces have distinct owners); a send buffer is reused once everyone has fetched from it
+      for (size_t k = s0; k < s1; k++) {
+        const Piece &pc = pieces[k]; uvaia_gpu_ctx *cx = g->ctx[(size_t)pc.owner]; auto &mo = g->m[(size_t)pc.owner];
+        GCHK(g, hipSetDevice(cx->device));
+        for (int d = 0; d < g->n; d++) if (g->m[(size_t)d].fetched_rec[bsel]) GCHK(g, hipStreamWaitEvent(cx->scan_streams[0], g->m[(size_t)d].fetched[bsel], 0));
+        GCTX(g, pc.owner, uvaia_gpu_shard_scan(cx, pc.first, pc.n, mo.send_cnt[bsel], mo.send_tmin[bsel]));
+        GCHK(g, hipEventRecord(mo.scanned[bsel], cx->scan_streams[0]));
+      }
+      // 2. every member fetches the rows of its queries from every owner, 3. and replays them in stream order
+      for (int d = 0; d < g->n; d++) {
+        auto &md = g->m[(size_t)d]; uvaia_gpu_ctx *cd = g->ctx[(size_t)d];
+        const size_t myrows = (size_t)(g->q1[(size_t)d] - g->q0[(size_t)d]);
+        GCHK(g, hipSetDevice(cd->device));
+        if (md.replayed_rec[bsel]) GCHK(g, hipStreamWaitEvent(md.copy, md.replayed[bsel], 0));      // the receive buffer's previous readers
+        for (size_t k = s0; k < s1 && myrows; k++) {
+          const Piece &pc = pieces[k]; auto &mo = g->m[(size_t)pc.owner];
+          const size_t tiles = (pc.first + pc.n + 63) / 64 - pc.first / 64, ppad = tiles * 64, slot = k - s0;
+          GCHK(g, hipStreamWaitEvent(md.copy, mo.scanned[bsel], 0));
+          GCHK(g, hipMemcpyPeerAsync(md.recv_cnt[bsel] + slot * myrows * (g->piece + 64), cd->device, mo.send_cnt[bsel] + (size_t)g->q0[(size_t)d] * ppad, g->ctx[(size_t)pc.owner]->device,
+                                     myrows * ppad * sizeof(int2), md.copy));
+          GCHK(g, hipMemcpyPeerAsync(md.recv_tmin[bsel] + slot * myrows * ((g->piece + 64) / 64), cd->device, mo.send_tmin[bsel] + (size_t)g->q0[(size_t)d] * tiles, g->ctx[(size_t)pc.owner]->device,
+                                     myrows * tiles * sizeof(int2), md.copy));
+        }
+        GCHK(g, hipEventRecord(md.fetched[bsel], md.copy)); md.fetched_rec[bsel] = true;
+        GCHK(g, hipStreamWaitEvent(cd->stream, md.fetched[bsel], 0));
+        for (size_t k = s0; k < s1 && myrows; k++) {
+          const Piece &pc = pieces[k]; const size_t slot = k - s0;
+          GCTX(g, d, uvaia_gpu_shard_replay(cd, md.recv_cnt[bsel] + slot * myrows * (g->piece + 64), md.recv_tmin[bsel] + slot * myrows * ((g->piece + 64) / 64), pc.first, pc.n,
+                                            ordinal0 + (int64_t)pc.first, g->q0[(size_t)d], g->q1[(size_t)d]));
+        }
+        GCHK(g, hipEventRecord(md.replayed[bsel], cd->stream)); md.replayed_rec[bsel] = true;
+      }
+    }
+  }
+  if (entered) {   // a reference is dumped if it entered the heap of ANY query (src/nearest.c:303-306): OR over the members
+    std::vector<uint8_t> part(total);
+    memset(entered, 0, total);
+    for (int i = 0; i < g->n; i++) {
+      GCHK(g, hipSetDevice(g->ctx[(size_t)i]->device));
+      if (g->m[(size_t)i].copy) GCHK(g, hipStreamSynchronize(g->m[(size_t)i].copy));
+      GCTX(g, i, uvaia_gpu_sync(g->ctx[(size_t)i]));
+      GCTX(g, i, uvaia_gpu_entered_flags(g->ctx[(size_t)i], part.data(), 0));
+      for (size_t x = 0; x < total; x++) entered[x] |= part[x];
+    }
+  }
+  return 0;
+}
+
+// one batch of the reference loop, sequences from host memory (uvaia_gpu_push for the group): every member packs the batch, the
+// scan of its pieces is shared out as above
+int uvaia_gpu_group_push(uvaia_gpu_group *g, const char *const *seq, const int *non_n, int n_ref, int64_t ordinal0, uint8_t *entered)
+{
+  if (!g) return UVAIA_GPU_EINVAL;
+  if (n_ref < 0 || (n_ref > 0 && !seq)) return gfail(g, UVAIA_GPU_EINVAL, "bad batch");
+  if (n_ref == 0) return 0;
+  if (g->n == 1) { GCHK(g, hipSetDevice(g->ctx[0]->device)); GCTX(g, 0, uvaia_gpu_push(g->ctx[0], seq, non_n, n_ref, ordinal0, entered)); return 0; }
+  int rc = uvaia_gpu_group_sync(g); if (rc) return rc;
+  rc = uvaia_gpu_group_db_clear(g); if (rc) return rc;
+  rc = uvaia_gpu_group_db_append(g, seq, non_n, n_ref); if (rc) return rc;
+  std::vector<uint8_t> ent((size_t)n_ref);
+  rc = uvaia_gpu_group_search_resident(g, (size_t)n_ref, ordinal0, entered ? entered : ent.data());
+  return rc;
+}
+
+// heaps of all queries, each from the member that replays it (arrays as uvaia_gpu_drain)
+int uvaia_gpu_group_drain(uvaia_gpu_group *g, int *n_items, int *max_incompatible, int *scores, int64_t *ordinals)
+{
+  if (!g || !n_items || !scores || !ordinals) return UVAIA_GPU_EINVAL;
+  if (g->n == 1) { GCHK(g, hipSetDevice(g->ctx[0]->device)); GCTX(g, 0, uvaia_gpu_drain(g->ctx[0], n_items, max_incompatible, scores, ordinals)); return 0; }
+  const size_t slots = (size_t)uvaia_gpu_heap_slots(g->ctx[0]) + 1;
+  std::vector<int> n((size_t)g->nq), T((size_t)g->nq), sc((size_t)g->nq * slots * 6);
+  std::vector<int64_t> od((size_t)g->nq * slots);
+  for (int i = 0; i < g->n; i++) {
+    GCHK(g, hipSetDevice(g->ctx[(size_t)i]->device));
+    if (g->m[(size_t)i].copy) GCHK(g, hipStreamSynchronize(g->m[(size_t)i].copy));
+    GCTX(g, i, uvaia_gpu_drain(g->ctx[(size_t)i], n.data(), T.data(), sc.data(), od.data()));
+    for (int q = g->q0[(size_t)i]; q < g->q1[(size_t)i]; q++) {
+      n_items[q] = n[(size_t)q];
+      if (max_incompatible) max_incompatible[q] = T[(size_t)q];
+      memcpy(scores + (size_t)q * slots * 6, sc.data() + (size_t)q * slots * 6, slots * 6 * sizeof(int));
+      memcpy(ordinals + (size_t)q * slots, od.data() + (size_t)q * slots, slots * sizeof(int64_t));
+    }
+  }
   return 0;
 }
 

@@ -168,7 +168,9 @@ def test_query_shards_equal_one_context(synth, acgt, gappy):
     whole database, give the heaps of one context over all queries -- with the snapshot exchanged pool by pool when the query set
     has constant-and-complete columns.  Three shards on one GPU, driven in lockstep."""
     from uvaia_amd import shards
-    refs, qs = synth
+    refs, _ = synth
+    _r, root, cols = F.synth_alignment(4, 2500, seed=11)
+    qs, _, _ = F.synth_alignment(150, 2500, seed=12, root=root, poly_cols=cols)      # three shards of whole super-tiles (64 queries)
     qs = list(qs)
     if gappy:
         qs = [bytearray(s) for s in qs]
@@ -184,7 +186,7 @@ def test_query_shards_equal_one_context(synth, acgt, gappy):
     engines = [capi.Engine.from_query(q, nbest=nbest, max_pool=512) for _ in range(world)]
     try:
         cuts = [shards.query_shard(q.ntax, r, world) for r in range(world)]
-        assert cuts == [(0, 16), (16, 32), (32, 40)]
+        assert cuts == [(0, 64), (64, 128), (128, 150)]
         for e in engines:
             e.db_append(refs)
         if not cons:
@@ -209,7 +211,7 @@ def test_query_shards_equal_one_context(synth, acgt, gappy):
                 e.push(refs[:10])
         assert np.array_equal(ent, ent_1)               # a reference is dumped if it entered a heap on any rank
         with pytest.raises(capi.GpuError):
-            engines[0].set_active_queries(8, 24)        # ranges start on a query tile
+            engines[0].set_active_queries(16, 80)       # ranges start on a super-tile of 64 queries
     finally:
         for e in engines:
             e.close()

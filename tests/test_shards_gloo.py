@@ -19,7 +19,7 @@ def _free_port():
 
 def _dataset(n_refs, gappy_queries):
     refs, root, cols = F.synth_alignment(n_refs, 1200, seed=51, p_snp=0.006)
-    qs, _, _ = F.synth_alignment(40, 1200, seed=52, root=root, poly_cols=cols, p_snp=0.006)
+    qs, _, _ = F.synth_alignment(150, 1200, seed=52, root=root, poly_cols=cols, p_snp=0.006)
     if gappy_queries:      # every column is invalid in some query: idx_c empty, the snapshot cannot influence anything
         qs = [bytearray(s) for s in qs]
         for i, s in enumerate(qs[:8]):
@@ -40,7 +40,7 @@ class ShardOracleEngine:
         self.q0, self.q1 = 0, query.ntax
 
     def set_active_queries(self, q0, q1):
-        assert q0 % 16 == 0 and 0 <= q0 < q1 <= self.q.ntax
+        assert q0 % 64 == 0 and 0 <= q0 < q1 <= self.q.ntax
         self.q0, self.q1 = q0, q1
 
     def max_tolerance(self):
@@ -92,7 +92,7 @@ def test_query_shard_boundaries():
             assert cuts[0][0] == 0 and max(c[1] for c in cuts) == nq
             for (a0, a1), (b0, b1) in zip(cuts, cuts[1:]):
                 assert a1 == b0 or (b0 == b1 == nq)              # contiguous; trailing ranks may be empty
-            assert all(c[0] % 16 == 0 or c[0] == nq for c in cuts)
+            assert all(c[0] % 64 == 0 or c[0] == nq for c in cuts)
     assert shards.query_shard(1000, 3, 8) == (384, 512)
 
 

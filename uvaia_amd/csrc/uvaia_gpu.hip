@@ -53,7 +53,6 @@ namespace {
 constexpr int HEAP_ENTRY = 8;          // 6 scores + 64-bit ordinal (lo, hi)
 constexpr int AMB_CAP = 11;            // alignment words with a partially ambiguous site remembered per sequence
 constexpr int AMB_STRIDE = AMB_CAP + 1;  // ints per QUERY: count (uncapped) + word indices
-constexpr int SCAN_LOCKSTEP = 2;       // scan3, qblock mode: word groups between two barriers of a block
 constexpr int AMB_ROW = 64;            // ints per REFERENCE side row (256 B, one coalesced wave load):
                                        //   [0] count (uncapped)  [1..11] word indices  [12 + 4k + p] plane p of the k-th listed word
 constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
@@ -83,10 +82,12 @@ struct uvaia_gpu_ctx {
   size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
   int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
   int2 *d_tmin[NBUF] = {};                // per (query, tile of 64 references): {smallest mismatch count, largest ACGT-match count}, one per counter buffer
+  int4 *d_rtb[NBUF] = {};                 // per reference of a slice: untruncated consensus pre-score (query sets with constant-and-complete columns), one per counter buffer
   int *d_mp[NBUF] = {};                   // --acgt: mismatches on the polymorphic columns per pair (dist_unique), one per counter buffer
   int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
   long long slice_tf[NBUF] = {};
   size_t subslice = 32768;                // resident search: pools are cut into slices of this size (exact: see search_resident)
+  bool subslice_forced = false;           // the length was given (tests): taken as it is
   int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16, n_idx_c = 0;
   size_t trim = 0;
   size_t max_pool = 0, pool_pad = 0;
@@ -101,7 +102,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_cls = nullptr;     // [W4*4][4]  cL, cH, constMask, polyMask
   uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][L,H,I,-][4]   compressed polymorphic columns of the queries
   uint32_t *d_stream = nullptr;  // per query tile: the dirty-word item stream of scan3_kernel (layout: see the kernel)
-  uint2 *d_sdir = nullptr;       // [nq_pad/16] {first dword of the tile's stream, number of group records}
+  uint32_t *d_sdir = nullptr;    // [nq_pad/64][16] per super-tile and wave: {first dword, number} of its group records and of its rare records
   int NP = 0, NP4 = 0;           // polymorphic columns counted densely
   int NR = 0, NR4 = 0, rare_max = -1;   // "rare" columns: all but <= rare_max queries carry the same base; sparse (items), groups follow the dense ones
   uint32_t *d_rmask = nullptr;   // [W4*4] mask of the rare columns
@@ -154,6 +155,7 @@ struct uvaia_gpu_ctx {
   // last batch (introspection)
   const uint4 *last_tiles = nullptr; const int *last_nonn = nullptr; int last_n = 0, last_rbegin = 0, last_ppad = 0, last_ntiles = 0;
   long long last_tile_first = 0;
+  const int4 *last_rt = nullptr;
   // stats
   std::vector<ScanEvt> evts;
   double scan_ms = 0, scan_bytes = 0; long long scan_launches = 0;
@@ -195,9 +197,9 @@ void fill_code_table(uint8_t *t)
 }  // namespace
 
 #include "kernels_pack.inc"
+#include "kernels_consensus.inc"
 #include "kernels_scan_history.inc"
 #include "kernels_scan3.inc"
-#include "kernels_consensus.inc"
 #include "kernels_replay.inc"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -262,11 +264,21 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
   return 0;
 }
 
+// rt (nullable unless the query set has constant-and-complete columns): the untruncated consensus pre-score of the slice's references,
+// by the packed-plane scans themselves or, next to the column-compressed scan, by consensus_rt_kernel on the same stream
 int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream,
-                 int2 *tmin, int r_lo, int r_hi, int *mp)
+                 int2 *tmin, int r_lo, int r_hi, int *mp, int4 *rt)
 {
   if (n_tiles <= 0) return 0;
   if (!stream) stream = c->stream;
+  const bool cons = c->n_idx_c > 0;
+  if (cons && !rt) return fail(c, UVAIA_GPU_ESTATE, "no buffer for the consensus pre-score");
+  const long long ptile_first = tile_first;       // packed tiles (tile_first may be renumbered for the derived planes below)
+  auto consensus_rt = [&]() {
+    if (!cons) return;
+    if (c->acgt) hipLaunchKernelGGL((consensus_rt_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, tiles, ptile_first, n_tiles, c->W4, c->d_cp, rt);
+    else         hipLaunchKernelGGL((consensus_rt_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, tiles, ptile_first, n_tiles, c->W4, c->d_cp, rt);
+  };
   const int n_qtiles = (c->nq + c->qt - 1) / c->qt;
   dim3 grid(scan_grid_size(n_qtiles, (n_tiles + 3) / 4)), block(256);
   ScanEvt ev_{};
@@ -285,25 +297,18 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
       tile_first = dtile_of(c, tile_first);
     }
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
-    const int qt_first = c->act_q0 / 16, nqt3 = (c->act_q1 + 15) / 16 - qt_first;
-    // lockstep blocks (4 query tiles x 1 reference tile, 2.4x less traffic): measured faster for 3..16 query tiles once the rebuild of
-    // the derived planes shares the memory system with the scan (rank 0 of 8 / 4 query shards: 9.26 -> 8.73, 7.16 -> 7.02 ms per step),
-    // even at 32 tiles, slower at 63 (4.86 -> 5.66 ms)
-    const int qblock = c->scan_qblock >= 0 ? c->scan_qblock : (nqt3 >= 3 && nqt3 <= 16 ? 1 : 0);
+    if (c->act_q0 % 64) return fail(c, UVAIA_GPU_ESTATE, "the scan works on super-tiles of 64 queries: active queries start at a multiple of 64");
+    const int st_first = c->act_q0 / 64, n_st = (c->act_q1 + 63) / 64 - st_first;
     const int R = c->scan_R;
-    dim3 grid3(qblock ? scan_grid_size((nqt3 + 3) / 4, (n_tiles + R - 1) / R) : scan_grid_size(nqt3, (n_tiles + 4 * R - 1) / (4 * R)));
-#define SCAN3_LAUNCH(A, RR) hipLaunchKernelGGL((scan3_kernel<16, A, RR>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, qt_first, qblock)
-    static const int abl = getenv("UVAIA_GPU_SCAN_ABLATE") ? atoi(getenv("UVAIA_GPU_SCAN_ABLATE")) : 0;     // TEMPORARY experiment: results invalid
-    if (R == 2 && abl && !c->acgt) {
-#define SCAN3_ABL(AB) hipLaunchKernelGGL((scan3_kernel<16, false, 2, AB>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, nqt3, tmin, r_lo, r_hi, mp, qt_first, qblock)
-      if (abl == 1) SCAN3_ABL(1); else if (abl == 2) SCAN3_ABL(2); else SCAN3_ABL(3);
-#undef SCAN3_ABL
-    } else
+    dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
+#define SCAN3_LAUNCH(A, RR) hipLaunchKernelGGL((scan3_kernel<16, A, RR>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
     if (R == 2) { if (c->acgt) SCAN3_LAUNCH(true, 2); else SCAN3_LAUNCH(false, 2); }
     else        { if (c->acgt) SCAN3_LAUNCH(true, 1); else SCAN3_LAUNCH(false, 1); }
 #undef SCAN3_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
+    consensus_rt();
+    HIPCHK(c, hipGetLastError());
     return 0;
   }
   if (c->scan_variant == 1) {
@@ -314,11 +319,15 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     else         hipLaunchKernelGGL((scan2v_kernel<QTV, RV, false>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
+    consensus_rt();
+    HIPCHK(c, hipGetLastError());
     return 0;
   }
-#define LAUNCH(K, QT) hipLaunchKernelGGL((K<QT>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi)
-  if (c->acgt) { switch (c->qt) { case 8: LAUNCH(scan2_acgt_kernel, 8); break; case 32: LAUNCH(scan2_acgt_kernel, 32); break; default: LAUNCH(scan2_acgt_kernel, 16); } }
-  else         { switch (c->qt) { case 8: LAUNCH(scan2_iupac_kernel, 8); break; case 32: LAUNCH(scan2_iupac_kernel, 32); break; default: LAUNCH(scan2_iupac_kernel, 16); } }
+#define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt)
+#define LAUNCH_QT(K, CN) switch (c->qt) { case 8: LAUNCH(K, 8, CN); break; case 32: LAUNCH(K, 32, CN); break; default: LAUNCH(K, 16, CN); }
+  if (c->acgt) { if (cons) { LAUNCH_QT(scan2_acgt_kernel, true) } else { LAUNCH_QT(scan2_acgt_kernel, false) } }
+  else         { if (cons) { LAUNCH_QT(scan2_iupac_kernel, true) } else { LAUNCH_QT(scan2_iupac_kernel, false) } }
+#undef LAUNCH_QT
 #undef LAUNCH
   HIPCHK(c, hipGetLastError());
   if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
@@ -356,7 +365,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
   }
   const int ppad = n_tiles * 64;
   hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(256), 0, c->stream, c->d_T, c->nq, c->d_snap);
-  if (c->n_idx_c > 0) {   // with no constant-and-complete column every pre-score counter is zero (common: gappy query sets)
+  if (c->n_idx_c > 0 && c->fullscan) {   // with no constant-and-complete column every pre-score counter is zero (common: gappy query sets)
     if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
     else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
   }
@@ -371,9 +380,9 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
     else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
   } else {
-    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0]);
+    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0], c->d_rtb[0]);
     if (rc) return rc;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rt, c->d_tr, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rtb[0], c->d_cp, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
                                     c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[0] : (const int2 *)nullptr, \
                                     c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
@@ -381,7 +390,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
 #undef REPLAY2
   }
   HIPCHK(c, hipGetLastError());
-  c->last_tiles = tiles; c->last_nonn = nonn_tile0; c->last_n = r_end - r_begin; c->last_rbegin = r_begin; c->last_ppad = ppad;
+  c->last_tiles = tiles; c->last_nonn = nonn_tile0; c->last_n = r_end - r_begin; c->last_rbegin = r_begin; c->last_ppad = ppad; c->last_rt = c->fullscan ? c->d_rt : c->d_rtb[0];
   c->last_ntiles = n_tiles; c->last_tile_first = tile_first;
   return 0;
 }
@@ -474,7 +483,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
-  for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); }
+  for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); if (c->d_rtb[i]) hipFree(c->d_rtb[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
   if (c->derive_stream) { hipStreamSynchronize(c->derive_stream); hipStreamDestroy(c->derive_stream); }
   for (auto &d : c->derive_chunks) hipEventDestroy(d.done);
@@ -517,7 +526,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
   // four-counter scan instead (32-bit counts, same results, slower)
   if (c->nchar > 49000) c->fullscan = true;
-  c->nq_pad = ((c->nq + 31) / 32) * 32;                      // multiple of every supported query tile
+  c->nq_pad = ((c->nq + 63) / 64) * 64;                      // multiple of every supported query tile and of the scan's super-tile of 64 queries
   c->max_pool = max_pool; c->pool_pad = ((max_pool + 63) / 64) * 64 + 64;
   c->pitch = ((size_t)c->nchar + 63) / 64 * 64;
   if ((size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) + 128 > 160 * 1024) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "nbest=%d does not fit the per-query LDS heap (max 5115)", heap_size); }
@@ -720,73 +729,93 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       // the item stream of every query tile (layout: see scan3_kernel)
       { const char *er = getenv("UVAIA_GPU_SCAN_R"); if (er) c->scan_R = atoi(er) == 1 ? 1 : 2; }
       const uint32_t row_b = 256u * (uint32_t)c->scan_R;      // bytes of a query's counter row in a wave's LDS block: 64 lanes x R tiles x 4
-      struct TileStream { std::vector<uint32_t> u; uint32_t nrec = 0, nrare = 0; };
-      const int n_qt = c->nq_pad / 16;
-      std::vector<TileStream> ts((size_t)n_qt);
+      // one stream per super-tile of 64 queries (scan3_kernel: four waves share the counters and the stream)
+      struct Rec { size_t at; uint32_t cost; };
+      struct TileStream { std::vector<uint32_t> u; std::vector<Rec> rec, rare; };
+      const int n_st = c->nq_pad / 64;
+      std::vector<TileStream> ts((size_t)n_st);
       std::vector<uint8_t> rare_groups_needed((size_t)std::max(c->NR4, 1), 0);
-      parallel_for(n_qt, [&](int t) {
-        std::vector<uint32_t> &strm = ts[(size_t)t].u;
+      parallel_for(n_st, [&](int st) {
+        TileStream &S = ts[(size_t)st];
+        std::vector<uint32_t> &strm = S.u;
+        std::vector<int> full, gen, wrd[4];
         for (int g = 0; g < c->W4; g++) {
-          const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
-          if ((fx | fy) == 0u) continue;
-          const uint32_t fa = (fx | (fx >> 16)) & 0xFFFFu;
-          // a dirty query whose non-ACGT / invalid sites of this group all lie in ONE 32-column word (an isolated N or ambiguity
-          // code: more than half of the partially dirty cases) gets a 4-dword "word item" instead of the 12-dword general one
-          uint32_t f4 = 0, f1 = 0;
-          for (uint32_t m = fa; m; m &= m - 1) {
-            const int q = __builtin_ctz(m);
-            const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
-            int words = 0;
-            for (int j = 0; j < 4; j++) words += (src[j] | src[4 + j]) != 0u;
-            if (words == 1) f1 |= 1u << q; else f4 |= 1u << q;
+          full.clear(); gen.clear(); for (auto &w : wrd) w.clear();
+          for (int ql = 0; ql < 64; ql++) {
+            const int q = st * 64 + ql, t = q / 16, b = q % 16;
+            const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
+            if ((fy >> b) & 1u) { full.push_back(ql); continue; }
+            if (!(((fx | (fx >> 16)) >> b) & 1u)) continue;
+            // a dirty query whose non-ACGT / invalid sites of this group all lie in ONE 32-column word (an isolated N or ambiguity
+            // code: more than half of the partially dirty cases) gets a 4-dword "word item" instead of the 12-dword general one
+            const uint32_t *src = qcv.data() + (size_t)q * crow + (size_t)g * 8;
+            int words = 0, last = 0;
+            for (int j = 0; j < 4; j++) if (src[j] | src[4 + j]) { words++; last = j; }
+            if (words == 1) wrd[last].push_back(ql); else gen.push_back(ql);
           }
-          uint32_t nw[4] = {0, 0, 0, 0};                // word items per word of the group, listed word by word
-          auto word_of = [&](int q) { const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8; int j = 0; while (!(src[j] | src[4 + j])) j++; return j; };
-          for (uint32_t m = f1; m; m &= m - 1) nw[word_of(__builtin_ctz(m))]++;
+          if (full.empty() && gen.empty() && wrd[0].empty() && wrd[1].empty() && wrd[2].empty() && wrd[3].empty()) continue;
           const size_t hdr = strm.size();
+          const uint32_t n_full4 = (uint32_t)(full.size() + 3) / 4u;
           strm.push_back((uint32_t)g * 2048u);
-          strm.push_back((uint32_t)(__builtin_popcount(fy) + 3) / 4u | nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19);
-          strm.push_back((uint32_t)__builtin_popcount(f4)); strm.push_back(0u);
-          for (uint32_t m = fy; m; m &= m - 1) strm.push_back((uint32_t)__builtin_ctz(m) * row_b);
-          while (strm.size() & 3) strm.push_back(16u * row_b);                                  // scratch row
-          for (uint32_t m = f4; m; m &= m - 1) {
-            const int q = __builtin_ctz(m);
-            const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
+          strm.push_back(n_full4 | (uint32_t)gen.size() << 16);
+          strm.push_back((uint32_t)wrd[0].size() | (uint32_t)wrd[1].size() << 8 | (uint32_t)wrd[2].size() << 16 | (uint32_t)wrd[3].size() << 24);
+          strm.push_back(0u);
+          for (int ql : full) strm.push_back((uint32_t)ql * row_b);
+          while (strm.size() & 3) strm.push_back(64u * row_b);                                  // scratch row
+          for (int ql : gen) {
+            const uint32_t *src = qcv.data() + (size_t)(st * 64 + ql) * crow + (size_t)g * 8;
             strm.insert(strm.end(), src, src + 8);
-            strm.push_back((uint32_t)q * row_b); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
+            strm.push_back((uint32_t)ql * row_b); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
           }
           for (int j = 0; j < 4; j++)
-            for (uint32_t m = f1; m; m &= m - 1) {
-              const int q = __builtin_ctz(m);
-              if (word_of(q) != j) continue;
-              const uint32_t *src = qcv.data() + (size_t)(t * 16 + q) * crow + (size_t)g * 8;
-              strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)q * row_b); strm.push_back(0u);
+            for (int ql : wrd[j]) {
+              const uint32_t *src = qcv.data() + (size_t)(st * 64 + ql) * crow + (size_t)g * 8;
+              strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)ql * row_b); strm.push_back(0u);
             }
           strm[hdr + 3] = (uint32_t)(strm.size() - hdr);
-          ts[(size_t)t].nrec++;
+          S.rec.push_back({hdr, 60u + 4u * n_full4 + 30u * (uint32_t)gen.size() + 14u * (uint32_t)(wrd[0].size() + wrd[1].size() + wrd[2].size() + wrd[3].size())});
         }
-        // rare records: { byte offset of the rare group's planes in the tile's gathered planes, word-item counts << 4, 0, 0 }
+        // the walk runs two headers ahead and takes a record's length from its header: a zero header of length 4 ends the group records
+        strm.push_back(0u); strm.push_back(0u); strm.push_back(0u); strm.push_back(4u);
+        strm.push_back(0u); strm.push_back(0u); strm.push_back(0u); strm.push_back(4u);
+        // rare records: { byte offset of the rare group's planes in the tile's gathered planes, word-item counts (8 bits each), 0, 0 }
         // + items { sites, their lo bits, their hi bits, LDS offset } listed word by word
         for (int r4 = 0; r4 < c->NR4; r4++) {
           uint32_t nw[4] = {0, 0, 0, 0};
-          for (int q = 0; q < 16; q++) for (const RareWord &rw : rare_q[(size_t)t * 16 + q]) if ((rw.word >> 2) == r4) nw[rw.word & 3]++;
+          for (int ql = 0; ql < 64; ql++) for (const RareWord &rw : rare_q[(size_t)st * 64 + ql]) if ((rw.word >> 2) == r4) nw[rw.word & 3]++;
           if (!(nw[0] | nw[1] | nw[2] | nw[3])) continue;
-          strm.push_back((uint32_t)(c->NP4 + r4) * 3072u); strm.push_back(nw[0] << 4 | nw[1] << 9 | nw[2] << 14 | nw[3] << 19); strm.push_back(0u); strm.push_back(0u);
+          S.rare.push_back({strm.size(), nw[0] + nw[1] + nw[2] + nw[3]});
+          strm.push_back((uint32_t)(c->NP4 + r4) * 3072u); strm.push_back(nw[0] | nw[1] << 8 | nw[2] << 16 | nw[3] << 24); strm.push_back(0u); strm.push_back(0u);
           for (int j = 0; j < 4; j++)
-            for (int q = 0; q < 16; q++) for (const RareWord &rw : rare_q[(size_t)t * 16 + q]) if (rw.word == r4 * 4 + j) {
-              strm.push_back(rw.m); strm.push_back(rw.l); strm.push_back(rw.h); strm.push_back((uint32_t)q * row_b);
+            for (int ql = 0; ql < 64; ql++) for (const RareWord &rw : rare_q[(size_t)st * 64 + ql]) if (rw.word == r4 * 4 + j) {
+              strm.push_back(rw.m); strm.push_back(rw.l); strm.push_back(rw.h); strm.push_back((uint32_t)ql * row_b);
             }
-          ts[(size_t)t].nrare++; rare_groups_needed[(size_t)r4] = 1;     // (a byte set to 1 by several threads)
+          rare_groups_needed[(size_t)r4] = 1;     // (a byte set to 1 by several threads)
         }
       });
-      std::vector<uint32_t> strm, sdir((size_t)n_qt * 2, 0u);
-      for (int t = 0; t < n_qt; t++) {
-        sdir[(size_t)t * 2] = (uint32_t)strm.size();
-        sdir[(size_t)t * 2 + 1] = ts[(size_t)t].nrec | (ts[(size_t)t].nrare << 16);
-        strm.insert(strm.end(), ts[(size_t)t].u.begin(), ts[(size_t)t].u.end());
-        // the header walk runs two records ahead and takes the length of a record from its header: a tile's records are followed by a
-        // zero header of length 4 (rare records hold no length), so that the look-ahead stays inside the stream
-        strm.push_back(0u); strm.push_back(0u); strm.push_back(0u); strm.push_back(4u);
+      std::vector<uint32_t> strm, sdir((size_t)n_st * 16, 0u);
+      auto split4 = [](const std::vector<Rec> &r, size_t base, size_t end_at, uint32_t *dir) {   // four contiguous shares of about the same cost
+        uint64_t total = 0;
+        for (const Rec &x : r) total += x.cost;
+        size_t i = 0; uint64_t done = 0;
+        for (int w = 0; w < 4; w++) {
+          const size_t i0 = i;
+          const uint64_t goal = total * (uint64_t)(w + 1) / 4u;
+          while (i < r.size() && (w == 3 || done + r[i].cost / 2 < goal)) { done += r[i].cost; i++; }
+          dir[2 * w] = (uint32_t)(base + (i0 < r.size() ? r[i0].at : end_at));
+          dir[2 * w + 1] = (uint32_t)(i - i0);
+        }
+      };
+      for (int st = 0; st < n_st; st++) {
+        const TileStream &S = ts[(size_t)st];
+        const size_t base = strm.size(), zero_hdr = S.rec.empty() ? 0 : 0;
+        (void)zero_hdr;
+        // a wave without records still looks at two headers: point it at the zero headers that end the group records
+        size_t end_at = S.u.size() - 8;
+        for (const Rec &x : S.rare) { end_at = std::min(end_at, x.at - 8); break; }
+        split4(S.rec, base, end_at, &sdir[(size_t)st * 16]);
+        split4(S.rare, base, S.u.size() - 8, &sdir[(size_t)st * 16 + 8]);
+        strm.insert(strm.end(), S.u.begin(), S.u.end());
       }
       for (uint8_t u : rare_groups_needed) c->need_r_groups += u;
       strm.resize(strm.size() + 64, 0u);                                // the kernel prefetches items and headers past the end
@@ -825,7 +854,9 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_ROW * sizeof(int)));
   if (!c->fullscan) { OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2))); c->slice_cap[0] = (size_t)c->nq_pad * c->pool_pad; }
   OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
-  { const char *env_sub = getenv("UVAIA_GPU_SUBSLICE"); if (env_sub && atol(env_sub) >= 64) c->subslice = (size_t)atol(env_sub); }
+  OPENCHK(hipMalloc(&c->d_rtb[0], c->pool_pad * sizeof(int4)));
+  OPENCHK(hipMemset(c->d_rtb[0], 0, c->pool_pad * sizeof(int4)));
+  { const char *env_sub = getenv("UVAIA_GPU_SUBSLICE"); if (env_sub && atol(env_sub) >= 64) { c->subslice = (size_t)atol(env_sub); c->subslice_forced = true; } }
   if (c->acgt && !c->fullscan && c->scan_variant == 2) OPENCHK(hipMalloc(&c->d_mp[0], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
@@ -1113,7 +1144,12 @@ static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first
   // rebuild inside the step: 6.18 -> 6.03, 7.24 -> 7.10, 9.89 -> 9.26 ms for rank 0 of 2, 4, 8 query shards; 63 tiles: worse).
   if (nqt <= 32) sub /= 2;
   if (nqt < 63) sub = std::min(pool, (sub * 63 / (size_t)std::max(nqt, 1) + 63) / 64 * 64);
-  if (nq_act < c->subslice_minq && (c->n_idx_c > 0 || nqt < 4)) sub = pool;
+  // At most three query tiles: the scan is bound by HBM and the replay has a handful of waves; what pays is running the replay
+  // of one slice next to the scan of the following ones (the pre-score no longer waits for the batch snapshot: DESIGN.md 2.3):
+  // four slices per pool, none below 65 536 references.
+  if (nqt < 4) sub = std::min(pool, std::max<size_t>(65536, ((pool + 3) / 4 + 63) / 64 * 64));
+  if (c->subslice_forced) sub = std::min(pool, c->subslice);
+  (void)nq_act;
   for (size_t a = first; a < first + n; a += pool) {
     const size_t pe = std::min(first + n, a + pool);
     // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
@@ -1253,8 +1289,8 @@ int uvaia_gpu_last_batch_scores(uvaia_gpu_ctx *c, int *out, int n_ref)
   }
   HIPCHK(c, hipMalloc(&d_out, bytes));
   dim3 grid((n_ref + 255) / 256, c->nq);
-  if (c->acgt) hipLaunchKernelGGL((batch_scores_kernel<true>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->d_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
-  else         hipLaunchKernelGGL((batch_scores_kernel<false>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->d_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
+  if (c->acgt) hipLaunchKernelGGL((batch_scores_kernel<true>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->last_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
+  else         hipLaunchKernelGGL((batch_scores_kernel<false>), grid, dim3(256), 0, c->stream, c->d_cnt, c->last_ppad, c->last_rt, c->last_nonn, c->last_rbegin, n_ref, c->nq, d_out);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1350,6 +1386,9 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
       if (c->d_tmin[buf]) hipFree(c->d_tmin[buf]);
       c->d_tmin[buf] = nullptr;
       HIPCHK(c, hipMalloc(&c->d_tmin[buf], (cap / 64) * sizeof(int2)));
+      if (c->d_rtb[buf]) hipFree(c->d_rtb[buf]);
+      c->d_rtb[buf] = nullptr;
+      HIPCHK(c, hipMalloc(&c->d_rtb[buf], (cap / (size_t)c->nq_pad + 64) * sizeof(int4)));
       if (c->d_mp[0] || (c->acgt && c->scan_variant == 2)) { if (c->d_mp[buf]) hipFree(c->d_mp[buf]); c->d_mp[buf] = nullptr; HIPCHK(c, hipMalloc(&c->d_mp[buf], cap * sizeof(int))); }
       c->slice_cap[buf] = cap;
     }
@@ -1366,7 +1405,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
   c->slice_scanned[buf] = true; c->slice_cons_done[buf] = false;
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, ss, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_mp[buf]);
+  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, ss, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_mp[buf], c->d_rtb[buf]);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->scan_done[buf], ss));
   return 0;
@@ -1386,17 +1425,12 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   if (re <= rb || q1 == q0) return 0;
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->scan_done[buf], 0));
   const int ppad = n_tiles * 64;
-  if (c->n_idx_c > 0 && !c->slice_cons_done[buf]) {     // once per slice: the pre-score does not depend on the query
-    if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
-    else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
-    c->slice_cons_done[buf] = true;
-  }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   const int lq_words = (c->replay_lq && !c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
   const int2 *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
                                   (c->scan_variant == 2 && c->shard_world == 1) ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
@@ -1405,7 +1439,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->replay_done[buf], c->stream));
   c->replay_recorded[buf] = true;
-  c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf;
+  c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf; c->last_rt = c->d_rtb[buf];
   return 0;
 }
 
@@ -1417,7 +1451,7 @@ int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stri
 int uvaia_gpu_set_active_queries(uvaia_gpu_ctx *c, int q0, int q1)
 {
   if (!c) return UVAIA_GPU_EINVAL;
-  if (q0 < 0 || q1 > c->nq || q1 <= q0 || (q0 % 16)) return fail(c, UVAIA_GPU_EINVAL, "active queries [%d,%d): need 0 <= q0 < q1 <= %d and q0 a multiple of 16", q0, q1, c->nq);
+  if (q0 < 0 || q1 > c->nq || q1 <= q0 || (q0 % 64)) return fail(c, UVAIA_GPU_EINVAL, "active queries [%d,%d): need 0 <= q0 < q1 <= %d and q0 a multiple of 64", q0, q1, c->nq);
   // (with reference shards the range only selects whose tolerances uvaia_gpu_max_tolerance looks at: every scan covers all queries)
   if ((c->fullscan || c->scan_variant != 2) && c->shard_world == 1) { if (q0 != 0 || q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "query shards need the default scan"); }
   c->act_q0 = q0; c->act_q1 = q1;
@@ -1483,7 +1517,7 @@ int uvaia_gpu_shard_scan(uvaia_gpu_ctx *c, size_t first, size_t n, void *cnt, vo
   }
   const int rb = (int)(first - (size_t)tf * 64);
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  return launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, (int2 *)cnt, n_tiles * 64, bytes, ss, (int2 *)tmin, rb, rb + (int)n, c->d_mp[0]);
+  return launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, (int2 *)cnt, n_tiles * 64, bytes, ss, (int2 *)tmin, rb, rb + (int)n, c->d_mp[0], c->d_rtb[0]);
 }
 
 int uvaia_gpu_scan_wait(uvaia_gpu_ctx *c)
@@ -1525,9 +1559,9 @@ int uvaia_gpu_shard_replay(uvaia_gpu_ctx *c, const void *cnt, const void *tmin, 
   const int n_tiles = (int)((first + n + 63) / 64 - first / 64), ppad = n_tiles * 64;
   if ((size_t)ppad > c->pool_pad) return fail(c, UVAIA_GPU_EINVAL, "range of %zu references above max_pool %zu", n, c->max_pool);
   const int rb = (int)(first - (size_t)tf * 64), re = rb + (int)n;
-  if (c->n_idx_c > 0) {
-    if (c->acgt) hipLaunchKernelGGL((consensus_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
-    else         hipLaunchKernelGGL((consensus_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_snap, c->d_rt, c->d_tr);
+  if (c->n_idx_c > 0) {   // the pre-score of the piece's references, from the packed planes this rank holds of every reference
+    if (c->acgt) hipLaunchKernelGGL((consensus_rt_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_rt);
+    else         hipLaunchKernelGGL((consensus_rt_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, c->d_db, tf, n_tiles, c->W4, c->d_cp, c->d_rt);
   }
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   const int lq_words = (c->replay_lq && !c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
@@ -1536,7 +1570,7 @@ int uvaia_gpu_shard_replay(uvaia_gpu_ctx *c, const void *cnt, const void *tmin, 
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
   // --acgt: dist_unique of the pairs that reach a heap is counted from the packed planes (the scan's per-pair count stays on the scanning rank)
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cntp, ppad, c->d_rt, c->d_tr, nonn, amb, rb, re, (long long)ordinal0, \
+#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cntp, ppad, c->d_rt, c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, tminp, (const int *)nullptr, lq_words, c->replay_prio, \
                                   (const uint4 *)nullptr, c->NP4 + c->NR4, c->NP4, 0, (const uint32_t *)nullptr)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }

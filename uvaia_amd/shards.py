@@ -17,9 +17,9 @@ critical path; the ring remains for databases that do not fit one GPU."""
 
 
 def query_shard(n_query, rank, world):
-    """[q0, q1) of this rank: contiguous, q0 a multiple of 16 (the scan's query tile); may be empty on high ranks."""
+    """[q0, q1) of this rank: contiguous, q0 a multiple of 64 (the scan's super-tile of queries); may be empty on high ranks."""
     per = -(-n_query // world)
-    per = -(-per // 16) * 16
+    per = -(-per // 64) * 64
     q0 = min(n_query, rank * per)
     q1 = min(n_query, q0 + per)
     return q0, q1

@@ -203,6 +203,37 @@ def single_gpu_workload(hostlib, n_query, refs, mode, nbest, pool, steps, warmup
     return out
 
 
+def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset, device):
+    """uvaiaball's radius search (src/ball.c:248-259, src/fastaseq.c:660-696) over an HBM-resident database: references per second,
+    and how many of them the search had to compare with the queries themselves (the others stop at the queries' consensus)."""
+    gen = hostlib.Synth(nchar, seed=seed, preset=preset)
+    qseqs, _ = gen.generate_bytes(QUERY_INDEX0, n_query)
+    t0 = time.time()
+    pq = hostlib.PreparedQuery(qseqs, ["query_%d" % i for i in range(n_query)], dist=dist, acgt=(mode == "acgt"), is_ball=True)
+    t1 = time.time()
+    eng = pq.open_engine(nbest=2, max_pool=65536, device=device)
+    eng.db_reserve(refs)
+    for a in range(0, refs, 8192):
+        n = min(8192, refs - a)
+        rows, non_n = gen.generate(a, n)
+        eng.db_append_block(rows, non_n)
+    md = eng.ball_resident(dist + 1)                      # warm-up, and the answer
+    eng.ball_asked(reset=True)
+    t_a = time.perf_counter()
+    for _ in range(steps):
+        eng.ball_resident(dist + 1, want=False)
+    elapsed = time.perf_counter() - t_a
+    asked = eng.ball_asked(reset=True) // max(1, steps)
+    sb = survey_bytes_per_ref(nchar, mode)
+    out = {"workload": "uvaiaball: %d queries (%d after pruning) x %d refs x %d cols, %s, radius %d" % (n_query, pq.ntax, refs, nchar, mode, dist),
+           "value": round(refs * steps / elapsed, 1), "unit": "ref-seqs/s", "ms_per_search": round(1e3 * elapsed / steps, 3), "steps": steps,
+           "kept": int((md <= dist).sum()), "compared_with_the_queries": int(asked),
+           "whole_search_GBps": round(refs * sb * steps / elapsed / 1e9, 1), "whole_search_frac_of_hbm_peak": round(refs * sb * steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+           "query_prepare_s": round(t1 - t0, 2)}
+    eng.close()
+    return out
+
+
 def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_timed, n_one):
     """The oracle's restatement of the reference loops (src/nearest.c:249-330) on the host cores, with the heaps in the state a long
     run spends its time in: `n_warm` references are fed untimed (heaps fill, tolerances settle: the early exits of
@@ -479,7 +510,7 @@ def main():
     eng.close()
 
     # ---- other resident-query counts, driver-timed in the same run (rank 0, N=1 only)
-    sweep = None
+    sweep = ball = None
     if rank == 0 and world == 1 and not emu and not args.no_sweep:
         sweep = []
         for nq_s, mode_s, steps_s in ((1, "iupac", 5), (4, "iupac", 5), (16, "iupac", 5), (10000, "acgt", 2)):
@@ -488,6 +519,7 @@ def main():
             if (nq_s, args.sweep_refs, args.nchar, args.nbest, mode_s) == (10000, 1000000, 29903, 100, "acgt"):
                 e["workload"] = "BASELINE config[2]: " + e["workload"]
             sweep.append(e)
+        ball = ball_workload(hostlib, 1000, args.sweep_refs, 2, "iupac", 3, args.nchar, args.seed, args.preset, local_rank)
 
     if rank == 0:
         out = {
@@ -520,6 +552,7 @@ def main():
             "cpu_baseline": cpu,
             "parity_check_on_timed_path": parity,
             "sweep": sweep,
+            "ball": ball,
         }
         print(json.dumps(out))
         sys.stdout.flush()

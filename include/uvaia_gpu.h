@@ -134,6 +134,11 @@ int uvaia_gpu_entered_flags (uvaia_gpu_ctx *ctx, uint8_t *out, int clear);   /* 
  * src/fastaseq.c:660-696) for one batch.  radius = cq->dist + 1.  mindist[i] receives what the reference leaves in
  * cq->mindist[c]; the caller keeps sequence i iff mindist[i] <= radius-1 (src/ball.c:255). */
 int uvaia_gpu_ball (uvaia_gpu_ctx *ctx, const char *const *seq, int n_ref, int radius, int *mindist);
+/* the same for references [first, first+n) of the resident database.  Both stop where the reference stops: a reference whose
+ * distance to the queries' consensus reaches the radius costs one pass over its packed planes, the queries are looked at only
+ * for the references the reference's own loop would look at them for (twice the consensus distance >= radius). */
+int uvaia_gpu_ball_resident (uvaia_gpu_ctx *ctx, size_t first, size_t n, int radius, int *mindist);
+unsigned long long uvaia_gpu_ball_asked (uvaia_gpu_ctx *ctx, int reset);    /* references sent on to the queries since the last reset */
 
 /* Query preprocessing: the O(Q^2) test of exclude_redundant_query_sequences (src/fastaseq.c:797-841, the
  * call at :806-808).  For each of n_seq sequences (<= max_pool) and each query q of the open set,

@@ -130,6 +130,29 @@ def test_ball_synthetic_many_radii():
                 assert np.array_equal(eng.ball(refs, q.dist + 1), md_want), (acgt, dist)
 
 
+@pytest.mark.parametrize("acgt", [False, True])
+def test_ball_over_the_resident_database_matches_oracle(acgt):
+    """uvaia_gpu_ball_resident on generator data at full genome length: radii from "nearly everything stops at the consensus" to
+    "every reference goes on to the queries" (more of them than one scan batch holds), ranges that start inside a tile."""
+    from uvaia_amd import hostlib
+    gen = hostlib.Synth(29903, seed=20241008, preset=1)
+    qs, _ = gen.generate_bytes(1 << 40, 24)
+    refs, _ = gen.generate_bytes(0, 1500)
+    refs = refs + qs[:6]                                   # some references identical to queries: distance 0
+    for dist in (0, 3, 40, 4000):
+        q = O.Query(qs, ["q%d" % i for i in range(len(qs))], dist=dist, acgt=acgt, is_ball=True)
+        md, keep = q.ball(refs, ambig_r=0.001)                 # (uvaiaball keeps references with at least nchar * A valid sites: nothing is dropped)
+        with capi.Engine.from_query(q, nbest=2, max_pool=512) as eng:
+            eng.db_reserve(len(refs))
+            eng.db_append(refs)
+            got = eng.ball_resident(q.dist + 1)
+            assert np.array_equal(got, md), dist
+            assert np.array_equal(eng.ball_resident(q.dist + 1, first=70, n=1000), md[70:1070])
+            asked = eng.ball_asked(reset=True)
+            assert (asked > 0) == (dist > 0) or dist == 0
+        assert keep.sum() == (md <= q.dist).sum()
+
+
 def test_uvaiaball_cli_matches_oracle(files):
     d, qn, qs, rnames, rseqs = files
     out = str(d / "ball_out")

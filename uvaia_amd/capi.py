@@ -14,7 +14,7 @@ NSCORE = 6
 SYMBOLS = [
     "uvaia_gpu_open", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
-    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_agree_on_polymorphic",
+    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_agree_on_polymorphic",
     "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
@@ -88,6 +88,8 @@ def load_library():
         "uvaia_gpu_search_resident": (C.c_int, [vp, C.c_size_t, C.c_int64, C.POINTER(C.c_uint8)]),
         "uvaia_gpu_sync": (C.c_int, [vp]),
         "uvaia_gpu_ball": (C.c_int, [vp, pp, C.c_int, C.c_int, pi]),
+        "uvaia_gpu_ball_resident": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int, pi]),
+        "uvaia_gpu_ball_asked": (C.c_ulonglong, [vp, C.c_int]),
         "uvaia_gpu_agree_on_polymorphic": (C.c_int, [vp, pp, C.c_int, C.POINTER(C.c_uint8)]),
         "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
         "uvaia_gpu_scan_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]),
@@ -400,6 +402,15 @@ class Engine:
         md = np.zeros(len(refs), dtype=np.int32)
         self._chk(self.L.uvaia_gpu_ball(self.ctx, _cstrs(refs), len(refs), int(radius), md.ctypes.data_as(C.POINTER(C.c_int))))
         return md
+
+    def ball_resident(self, radius, first=0, n=None, want=True):
+        n = self.db_size() - first if n is None else n
+        md = np.zeros(n, dtype=np.int32) if want else None
+        self._chk(self.L.uvaia_gpu_ball_resident(self.ctx, int(first), int(n), int(radius), md.ctypes.data_as(C.POINTER(C.c_int)) if want else None))
+        return md
+
+    def ball_asked(self, reset=False):
+        return int(self.L.uvaia_gpu_ball_asked(self.ctx, int(reset)))
 
 
 def finalise_heaps(n, scores, ordinals):

@@ -120,6 +120,7 @@ struct uvaia_gpu_ctx {
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
   int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)
+  int scan_NW = 8;               // waves per block of scan3_kernel = shares a super-tile's records are cut into
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
@@ -133,8 +134,8 @@ struct uvaia_gpu_ctx {
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
   uint32_t *d_cpm = nullptr;     // consensus restricted to idx_m (radius search)
   uint32_t *d_qpoly = nullptr;   // queries restricted to idx (radius search), [nq_pad][W4][4][NQ]
-  uint32_t *d_cmrows = nullptr;  // 32 pseudo-query rows: [0] consensus on idx_c, [1] consensus on idx_m (radius search)
-  int4 *d_cnt_cm = nullptr; size_t cnt_cm_cap = 0; int *d_mindist = nullptr;
+  int *d_mindist = nullptr, *d_ball_list = nullptr, *d_ball_cdist = nullptr, *d_ball_n = nullptr; size_t ball_cap = 0;   // radius search: results, the references that go on to the queries
+  uint4 *d_ball_tiles = nullptr; size_t ball_tiles_cap = 0; unsigned long long ball_asked = 0;
   std::vector<uint32_t> h_qp_poly_src;  // kept to build d_qpoly lazily
   // heaps / state
   int *d_heap = nullptr, *d_n = nullptr, *d_T = nullptr, *d_snap = nullptr, *d_err = nullptr;
@@ -301,9 +302,17 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int st_first = c->act_q0 / 64, n_st = (c->act_q1 + 63) / 64 - st_first;
     const int R = c->scan_R;
     dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
-#define SCAN3_LAUNCH(A, RR) hipLaunchKernelGGL((scan3_kernel<16, A, RR>), grid3, block, c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
-    if (R == 2) { if (c->acgt) SCAN3_LAUNCH(true, 2); else SCAN3_LAUNCH(false, 2); }
-    else        { if (c->acgt) SCAN3_LAUNCH(true, 1); else SCAN3_LAUNCH(false, 1); }
+#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
+#define SCAN3_NW(A, RR) { if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR); else SCAN3_LAUNCH(4, A, RR); }
+    static const int abl = getenv("UVAIA_GPU_SCAN_ABLATE") ? atoi(getenv("UVAIA_GPU_SCAN_ABLATE")) : 0;     // TEMPORARY experiment: results invalid
+    if (R == 2 && abl && !c->acgt && c->scan_NW == 8) {
+      if (abl == 1) hipLaunchKernelGGL((scan3_kernel<8, false, 2, 1>), grid3, dim3(512), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first);
+      else if (abl == 2) hipLaunchKernelGGL((scan3_kernel<8, false, 2, 2>), grid3, dim3(512), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first);
+      else hipLaunchKernelGGL((scan3_kernel<8, false, 2, 3>), grid3, dim3(512), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first);
+    } else
+    if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
+    else        { if (c->acgt) SCAN3_NW(true, 1) else SCAN3_NW(false, 1) }
+#undef SCAN3_NW
 #undef SCAN3_LAUNCH
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
@@ -479,7 +488,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   void *dev[] = {c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
-                 c->d_batch_tot, c->d_db_tot, c->d_cmrows, c->d_cnt_cm, c->d_mindist, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+                 c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -728,6 +737,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
       { const char *er = getenv("UVAIA_GPU_SCAN_R"); if (er) c->scan_R = atoi(er) == 1 ? 1 : 2; }
+      { const char *er = getenv("UVAIA_GPU_SCAN_NW"); if (er) c->scan_NW = atoi(er) == 4 ? 4 : 8; }
+      const int NWs = c->scan_NW;
       const uint32_t row_b = 256u * (uint32_t)c->scan_R;      // bytes of a query's counter row in a wave's LDS block: 64 lanes x R tiles x 4
       // one stream per super-tile of 64 queries (scan3_kernel: four waves share the counters and the stream)
       struct Rec { size_t at; uint32_t cost; };
@@ -793,15 +804,15 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           rare_groups_needed[(size_t)r4] = 1;     // (a byte set to 1 by several threads)
         }
       });
-      std::vector<uint32_t> strm, sdir((size_t)n_st * 16, 0u);
-      auto split4 = [](const std::vector<Rec> &r, size_t base, size_t end_at, uint32_t *dir) {   // four contiguous shares of about the same cost
+      std::vector<uint32_t> strm, sdir((size_t)n_st * 4 * NWs, 0u);
+      auto split4 = [NWs](const std::vector<Rec> &r, size_t base, size_t end_at, uint32_t *dir) {   // NW contiguous shares of about the same cost
         uint64_t total = 0;
         for (const Rec &x : r) total += x.cost;
         size_t i = 0; uint64_t done = 0;
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < NWs; w++) {
           const size_t i0 = i;
-          const uint64_t goal = total * (uint64_t)(w + 1) / 4u;
-          while (i < r.size() && (w == 3 || done + r[i].cost / 2 < goal)) { done += r[i].cost; i++; }
+          const uint64_t goal = total * (uint64_t)(w + 1) / (uint64_t)NWs;
+          while (i < r.size() && (w == NWs - 1 || done + r[i].cost / 2 < goal)) { done += r[i].cost; i++; }
           dir[2 * w] = (uint32_t)(base + (i0 < r.size() ? r[i0].at : end_at));
           dir[2 * w + 1] = (uint32_t)(i - i0);
         }
@@ -813,8 +824,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         // a wave without records still looks at two headers: point it at the zero headers that end the group records
         size_t end_at = S.u.size() - 8;
         for (const Rec &x : S.rare) { end_at = std::min(end_at, x.at - 8); break; }
-        split4(S.rec, base, end_at, &sdir[(size_t)st * 16]);
-        split4(S.rare, base, S.u.size() - 8, &sdir[(size_t)st * 16 + 8]);
+        split4(S.rec, base, end_at, &sdir[(size_t)st * 4 * NWs]);
+        split4(S.rare, base, S.u.size() - 8, &sdir[(size_t)st * 4 * NWs + 2 * NWs]);
         strm.insert(strm.end(), S.u.begin(), S.u.end());
       }
       for (uint8_t u : rare_groups_needed) c->need_r_groups += u;
@@ -827,9 +838,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_qpoly, qpoly.size() * 4)); OPENCHK(hipMemcpy(c->d_qpoly, qpoly.data(), qpoly.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cp, cp.size() * 4)); OPENCHK(hipMemcpy(c->d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cpm, cpm.size() * 4)); OPENCHK(hipMemcpy(c->d_cpm, cpm.data(), cpm.size() * 4, hipMemcpyHostToDevice));
-  OPENCHK(hipMalloc(&c->d_cmrows, 32 * row_words * 4)); OPENCHK(hipMemset(c->d_cmrows, 0, 32 * row_words * 4));
-  OPENCHK(hipMemcpy(c->d_cmrows, cp.data(), row_words * 4, hipMemcpyHostToDevice));
-  OPENCHK(hipMemcpy(c->d_cmrows + row_words, cpm.data(), row_words * 4, hipMemcpyHostToDevice));
 
   // ---- state
   OPENCHK(hipMalloc(&c->d_heap, (size_t)c->nq * (c->k + 1) * HEAP_ENTRY * sizeof(int)));
@@ -1827,6 +1835,56 @@ int uvaia_gpu_group_drain(uvaia_gpu_group *g, int *n_items, int *max_incompatibl
   return 0;
 }
 
+// radius search over references [r_lo, r_hi) (relative to tile tile_first of `tiles`): stage 1 for all, the queries for the few
+static int ball_range(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int n_tiles, int r_lo, int r_hi, int radius, int *mindist_host)
+{
+  const int n = r_hi - r_lo;
+  if (n <= 0) return 0;
+  if (!c->d_mindist || c->ball_cap < (size_t)n_tiles * 64) {
+    if (c->d_mindist) { hipFree(c->d_mindist); hipFree(c->d_ball_list); hipFree(c->d_ball_cdist); c->d_mindist = nullptr; }
+    c->ball_cap = std::max<size_t>((size_t)n_tiles * 64, c->pool_pad);
+    HIPCHK(c, hipMalloc(&c->d_mindist, c->ball_cap * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_ball_list, c->ball_cap * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_ball_cdist, c->ball_cap * sizeof(int)));
+    if (!c->d_ball_n) HIPCHK(c, hipMalloc(&c->d_ball_n, sizeof(int)));
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_ball_n, 0, sizeof(int), c->stream));
+  if (c->acgt) hipLaunchKernelGGL((ball_stage1_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_cpm, radius, r_lo, r_hi, c->d_mindist, c->d_ball_cdist, c->d_ball_list, c->d_ball_n);
+  else         hipLaunchKernelGGL((ball_stage1_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, c->stream, tiles, tile_first, n_tiles, c->W4, c->d_cp, c->d_cpm, radius, r_lo, r_hi, c->d_mindist, c->d_ball_cdist, c->d_ball_list, c->d_ball_n);
+  HIPCHK(c, hipGetLastError());
+  int n_ask = 0;
+  HIPCHK(c, hipMemcpyAsync(&n_ask, c->d_ball_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->ball_asked += (unsigned long long)n_ask;
+  // the references whose answer depends on the queries, max_pool at a time (the order of the list does not matter: every entry
+  // writes its own result)
+  for (int done = 0; done < n_ask;) {
+    const int m = std::min<int>(n_ask - done, (int)(c->pool_pad - 64)), mt = (m + 63) / 64, ppad = mt * 64;
+    const size_t tile_u4 = (size_t)c->W4 * c->P * 64;
+    if (c->ball_tiles_cap < (size_t)mt) {
+      if (c->d_ball_tiles) hipFree(c->d_ball_tiles);
+      c->d_ball_tiles = nullptr;
+      HIPCHK(c, hipMalloc(&c->d_ball_tiles, (size_t)mt * tile_u4 * sizeof(uint4)));
+      c->ball_tiles_cap = (size_t)mt;
+    }
+    if (c->acgt) hipLaunchKernelGGL((gather_refs_kernel<3>), dim3(mt), dim3(256), 0, c->stream, tiles, tile_first, c->W4, c->d_ball_list + done, m, c->d_ball_tiles);
+    else         hipLaunchKernelGGL((gather_refs_kernel<4>), dim3(mt), dim3(256), 0, c->stream, tiles, tile_first, c->W4, c->d_ball_list + done, m, c->d_ball_tiles);
+    HIPCHK(c, hipGetLastError());
+    int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
+    const bool prof = c->profile; c->profile = false;     // not the nearest-neighbour scan the statistics describe
+    rc = launch_scan(c, c->d_ball_tiles, 0, mt, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
+    c->profile = prof;
+    if (rc) return rc;
+    if (c->acgt) hipLaunchKernelGGL((ball_finish_kernel<true>), dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_cnt, ppad, c->nq, c->d_ball_list + done, c->d_ball_cdist + done, m, radius, r_lo, c->d_mindist);
+    else         hipLaunchKernelGGL((ball_finish_kernel<false>), dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_cnt, ppad, c->nq, c->d_ball_list + done, c->d_ball_cdist + done, m, radius, r_lo, c->d_mindist);
+    HIPCHK(c, hipGetLastError());
+    done += m;
+  }
+  if (mindist_host) HIPCHK(c, hipMemcpyAsync(mindist_host, c->d_mindist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radius, int *mindist)
 {
   if (!c) return UVAIA_GPU_EINVAL;
@@ -1836,24 +1894,27 @@ int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radi
   if (n_ref == 0) return 0;
   int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
-  const int n_tiles = (n_ref + 63) / 64, ppad = n_tiles * 64;
-  rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
-  if (c->cnt_cm_cap < (size_t)32 * c->pool_pad) {
-    if (c->d_cnt_cm) HIPCHK(c, hipFree(c->d_cnt_cm));
-    HIPCHK(c, hipMalloc(&c->d_cnt_cm, (size_t)32 * c->pool_pad * sizeof(int4))); c->cnt_cm_cap = (size_t)32 * c->pool_pad;
-    if (!c->d_mindist) HIPCHK(c, hipMalloc(&c->d_mindist, c->pool_pad * sizeof(int)));
+  return ball_range(c, c->d_batch, 0, (n_ref + 63) / 64, 0, n_ref, radius, mindist);
+}
+
+// the same over references [first, first + n) of the resident database (uvaia_gpu_db_append*): mindist[i] for reference first + i
+int uvaia_gpu_ball_resident(uvaia_gpu_ctx *c, size_t first, size_t n, int radius, int *mindist)
+{
+  if (!c) return UVAIA_GPU_EINVAL;
+  if (first + n > c->db_n) return fail(c, UVAIA_GPU_EINVAL, "range [%zu,+%zu) outside the database", first, n);
+  if (c->act_q0 != 0 || c->act_q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "the radius search acts on the whole query set");
+  for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
+  const size_t step = (size_t)1 << 22;                       // stage 1 needs no more than 12 bytes per reference of work space
+  for (size_t a = first; a < first + n; a += step) {
+    const size_t b = std::min(first + n, a + step);
+    const long long tf = (long long)(a / 64);
+    int rc = ball_range(c, c->d_db, tf, (int)((b + 63) / 64 - a / 64), (int)(a - (size_t)tf * 64), (int)(b - (size_t)tf * 64), radius, mindist ? mindist + (a - first) : nullptr);
+    if (rc) return rc;
   }
-  const bool prof = c->profile; c->profile = false;     // these launches are not the nearest-neighbour scan the statistics describe
-  rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_cmrows, 2, c->d_cnt_cm, ppad, 0.0);
-  if (!rc) rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
-  c->profile = prof;
-  if (rc) return rc;
-  if (c->acgt) hipLaunchKernelGGL((ball_reduce_kernel<true>), dim3((n_ref + 255) / 256), dim3(256), 0, c->stream, c->d_cnt_cm, ppad, c->d_cnt, ppad, c->nq, n_ref, radius, c->d_mindist);
-  else         hipLaunchKernelGGL((ball_reduce_kernel<false>), dim3((n_ref + 255) / 256), dim3(256), 0, c->stream, c->d_cnt_cm, ppad, c->d_cnt, ppad, c->nq, n_ref, radius, c->d_mindist);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(mindist, c->d_mindist, (size_t)n_ref * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
+
+// references the last radius searches sent on to the queries (since the last call with reset != 0)
+unsigned long long uvaia_gpu_ball_asked(uvaia_gpu_ctx *c, int reset) { if (!c) return 0; const unsigned long long v = c->ball_asked; if (reset) c->ball_asked = 0; return v; }
 
 }  // extern "C"

@@ -121,6 +121,7 @@ struct uvaia_gpu_ctx {
   int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
   int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)
   int scan_NW = 8;               // waves per block of scan3_kernel = shares a super-tile's records are cut into
+  int scan_QS = 64;              // queries of a super-tile of scan3_kernel (64 or 128; 128 goes with 16 waves per block)
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
@@ -298,17 +299,16 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
       tile_first = dtile_of(c, tile_first);
     }
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
-    if (c->act_q0 % 64) return fail(c, UVAIA_GPU_ESTATE, "the scan works on super-tiles of 64 queries: active queries start at a multiple of 64");
-    const int st_first = c->act_q0 / 64, n_st = (c->act_q1 + 63) / 64 - st_first;
+    const int QS = c->scan_QS;
+    if (c->act_q0 % QS) return fail(c, UVAIA_GPU_ESTATE, "the scan works on super-tiles of %d queries: active queries start at a multiple of that", QS);
+    const int st_first = c->act_q0 / QS, n_st = (c->act_q1 + QS - 1) / QS - st_first;
     const int R = c->scan_R;
     dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
-#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
-#define SCAN3_NW(A, RR) { if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR); else SCAN3_LAUNCH(4, A, RR); }
+#define SCAN3_LAUNCH(NWW, A, RR, QQ, AB) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR, QQ, AB>), grid3, dim3(64 * NWW), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
+#define SCAN3_NW(A, RR) { if (QS == 128) SCAN3_LAUNCH(16, A, RR, 128, 0); else if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR, 64, 0); else SCAN3_LAUNCH(4, A, RR, 64, 0); }
     static const int abl = getenv("UVAIA_GPU_SCAN_ABLATE") ? atoi(getenv("UVAIA_GPU_SCAN_ABLATE")) : 0;     // TEMPORARY experiment: results invalid
     if (R == 2 && abl && !c->acgt && c->scan_NW == 8) {
-      if (abl == 1) hipLaunchKernelGGL((scan3_kernel<8, false, 2, 1>), grid3, dim3(512), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first);
-      else if (abl == 2) hipLaunchKernelGGL((scan3_kernel<8, false, 2, 2>), grid3, dim3(512), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first);
-      else hipLaunchKernelGGL((scan3_kernel<8, false, 2, 3>), grid3, dim3(512), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first);
+      if (abl == 1) SCAN3_LAUNCH(8, false, 2, 64, 1); else if (abl == 2) SCAN3_LAUNCH(8, false, 2, 64, 2); else SCAN3_LAUNCH(8, false, 2, 64, 3);
     } else
     if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
     else        { if (c->acgt) SCAN3_NW(true, 1) else SCAN3_NW(false, 1) }
@@ -535,7 +535,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
   // four-counter scan instead (32-bit counts, same results, slower)
   if (c->nchar > 49000) c->fullscan = true;
-  c->nq_pad = ((c->nq + 63) / 64) * 64;                      // multiple of every supported query tile and of the scan's super-tile of 64 queries
+  c->nq_pad = ((c->nq + 127) / 128) * 128;                   // multiple of every supported query tile and of the scan's super-tiles (64 or 128 queries)
   c->max_pool = max_pool; c->pool_pad = ((max_pool + 63) / 64) * 64 + 64;
   c->pitch = ((size_t)c->nchar + 63) / 64 * 64;
   if ((size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) + 128 > 160 * 1024) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "nbest=%d does not fit the per-query LDS heap (max 5115)", heap_size); }
@@ -737,13 +737,15 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
       { const char *er = getenv("UVAIA_GPU_SCAN_R"); if (er) c->scan_R = atoi(er) == 1 ? 1 : 2; }
-      { const char *er = getenv("UVAIA_GPU_SCAN_NW"); if (er) c->scan_NW = atoi(er) == 4 ? 4 : 8; }
-      const int NWs = c->scan_NW;
+      { const char *er = getenv("UVAIA_GPU_SCAN_NW"); if (er) c->scan_NW = atoi(er) == 4 ? 4 : atoi(er) == 16 ? 16 : 8; }
+      { const char *er = getenv("UVAIA_GPU_SCAN_QS"); if (er) c->scan_QS = atoi(er) == 128 ? 128 : 64; }
+      if (c->scan_QS == 128) c->scan_NW = 16; else if (c->scan_NW == 16) c->scan_NW = 8;
+      const int NWs = c->scan_NW, QS = c->scan_QS;
       const uint32_t row_b = 256u * (uint32_t)c->scan_R;      // bytes of a query's counter row in a wave's LDS block: 64 lanes x R tiles x 4
       // one stream per super-tile of 64 queries (scan3_kernel: four waves share the counters and the stream)
       struct Rec { size_t at; uint32_t cost; };
       struct TileStream { std::vector<uint32_t> u; std::vector<Rec> rec, rare; };
-      const int n_st = c->nq_pad / 64;
+      const int n_st = c->nq_pad / QS;
       std::vector<TileStream> ts((size_t)n_st);
       std::vector<uint8_t> rare_groups_needed((size_t)std::max(c->NR4, 1), 0);
       parallel_for(n_st, [&](int st) {
@@ -752,8 +754,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         std::vector<int> full, gen, wrd[4];
         for (int g = 0; g < c->W4; g++) {
           full.clear(); gen.clear(); for (auto &w : wrd) w.clear();
-          for (int ql = 0; ql < 64; ql++) {
-            const int q = st * 64 + ql, t = q / 16, b = q % 16;
+          for (int ql = 0; ql < QS; ql++) {
+            const int q = st * QS + ql, t = q / 16, b = q % 16;
             const uint32_t fx = flg[((size_t)t * c->W4 + g) * 2], fy = flg[((size_t)t * c->W4 + g) * 2 + 1];
             if ((fy >> b) & 1u) { full.push_back(ql); continue; }
             if (!(((fx | (fx >> 16)) >> b) & 1u)) continue;
@@ -772,15 +774,15 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
           strm.push_back((uint32_t)wrd[0].size() | (uint32_t)wrd[1].size() << 8 | (uint32_t)wrd[2].size() << 16 | (uint32_t)wrd[3].size() << 24);
           strm.push_back(0u);
           for (int ql : full) strm.push_back((uint32_t)ql * row_b);
-          while (strm.size() & 3) strm.push_back(64u * row_b);                                  // scratch row
+          while (strm.size() & 3) strm.push_back((uint32_t)QS * row_b);                         // scratch row
           for (int ql : gen) {
-            const uint32_t *src = qcv.data() + (size_t)(st * 64 + ql) * crow + (size_t)g * 8;
+            const uint32_t *src = qcv.data() + (size_t)(st * QS + ql) * crow + (size_t)g * 8;
             strm.insert(strm.end(), src, src + 8);
             strm.push_back((uint32_t)ql * row_b); strm.push_back(0u); strm.push_back(0u); strm.push_back(0u);
           }
           for (int j = 0; j < 4; j++)
             for (int ql : wrd[j]) {
-              const uint32_t *src = qcv.data() + (size_t)(st * 64 + ql) * crow + (size_t)g * 8;
+              const uint32_t *src = qcv.data() + (size_t)(st * QS + ql) * crow + (size_t)g * 8;
               strm.push_back(src[j]); strm.push_back(src[4 + j]); strm.push_back((uint32_t)ql * row_b); strm.push_back(0u);
             }
           strm[hdr + 3] = (uint32_t)(strm.size() - hdr);
@@ -793,12 +795,12 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         // + items { sites, their lo bits, their hi bits, LDS offset } listed word by word
         for (int r4 = 0; r4 < c->NR4; r4++) {
           uint32_t nw[4] = {0, 0, 0, 0};
-          for (int ql = 0; ql < 64; ql++) for (const RareWord &rw : rare_q[(size_t)st * 64 + ql]) if ((rw.word >> 2) == r4) nw[rw.word & 3]++;
+          for (int ql = 0; ql < QS; ql++) for (const RareWord &rw : rare_q[(size_t)st * QS + ql]) if ((rw.word >> 2) == r4) nw[rw.word & 3]++;
           if (!(nw[0] | nw[1] | nw[2] | nw[3])) continue;
           S.rare.push_back({strm.size(), nw[0] + nw[1] + nw[2] + nw[3]});
           strm.push_back((uint32_t)(c->NP4 + r4) * 3072u); strm.push_back(nw[0] | nw[1] << 8 | nw[2] << 16 | nw[3] << 24); strm.push_back(0u); strm.push_back(0u);
           for (int j = 0; j < 4; j++)
-            for (int ql = 0; ql < 64; ql++) for (const RareWord &rw : rare_q[(size_t)st * 64 + ql]) if (rw.word == r4 * 4 + j) {
+            for (int ql = 0; ql < QS; ql++) for (const RareWord &rw : rare_q[(size_t)st * QS + ql]) if (rw.word == r4 * 4 + j) {
               strm.push_back(rw.m); strm.push_back(rw.l); strm.push_back(rw.h); strm.push_back((uint32_t)ql * row_b);
             }
           rare_groups_needed[(size_t)r4] = 1;     // (a byte set to 1 by several threads)

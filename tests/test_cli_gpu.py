@@ -148,8 +148,7 @@ def test_ball_over_the_resident_database_matches_oracle(acgt):
             got = eng.ball_resident(q.dist + 1)
             assert np.array_equal(got, md), dist
             assert np.array_equal(eng.ball_resident(q.dist + 1, first=70, n=1000), md[70:1070])
-            asked = eng.ball_asked(reset=True)
-            assert (asked > 0) == (dist > 0) or dist == 0
+            assert eng.ball_asked(reset=True) <= 2 * len(refs)          # two searches: at most every reference goes on to the queries
         assert keep.sum() == (md <= q.dist).sum()
 
 

@@ -281,8 +281,9 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     if (c->acgt) hipLaunchKernelGGL((consensus_rt_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, tiles, ptile_first, n_tiles, c->W4, c->d_cp, rt);
     else         hipLaunchKernelGGL((consensus_rt_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, tiles, ptile_first, n_tiles, c->W4, c->d_cp, rt);
   };
-  const int n_qtiles = (c->nq + c->qt - 1) / c->qt;
-  dim3 grid(scan_grid_size(n_qtiles, (n_tiles + 3) / 4)), block(256);
+  const int qt2 = c->qt == 8 ? 8 : 16;                           // query tile of the packed-plane scans (their partial sums share LDS: no 32)
+  const int n_qtiles = (c->nq + qt2 - 1) / qt2;
+  dim3 grid(scan_grid_size(n_qtiles, n_tiles)), block(256);      // the packed-plane scans: one block per (query tile, tile of references)
   ScanEvt ev_{};
   if (c->profile) {
     HIPCHK(c, hipEventCreate(&ev_.a)); HIPCHK(c, hipEventCreate(&ev_.b));
@@ -333,7 +334,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     return 0;
   }
 #define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt)
-#define LAUNCH_QT(K, CN) switch (c->qt) { case 8: LAUNCH(K, 8, CN); break; case 32: LAUNCH(K, 32, CN); break; default: LAUNCH(K, 16, CN); }
+#define LAUNCH_QT(K, CN) switch (qt2) { case 8: LAUNCH(K, 8, CN); break; default: LAUNCH(K, 16, CN); }
   if (c->acgt) { if (cons) { LAUNCH_QT(scan2_acgt_kernel, true) } else { LAUNCH_QT(scan2_acgt_kernel, false) } }
   else         { if (cons) { LAUNCH_QT(scan2_iupac_kernel, true) } else { LAUNCH_QT(scan2_iupac_kernel, false) } }
 #undef LAUNCH_QT
@@ -1162,6 +1163,17 @@ static std::vector<SubSlice> plan_subslices(const uvaia_gpu_ctx *c, size_t first
   (void)nq_act;
   for (size_t a = first; a < first + n; a += pool) {
     const size_t pe = std::min(first + n, a + pool);
+    if (nqt < 4 && !c->subslice_forced && pe - a >= 8 * 65536) {
+      // Few queries, a long pool: the replay of a pool's FIRST references is the expensive one (the heaps fill and turn over fast,
+      // every admission a dependent round trip to memory for a handful of waves) and the replay of its LAST slice is exposed.  A
+      // short head lets the first start early, next to the scans of the rest; a short tail keeps the exposed part small.
+      const size_t head = 65536, tail = 65536, mid = pe - a - head - tail, nm = std::max<size_t>(1, (mid + sub / 2) / sub);
+      const size_t each = ((mid + nm - 1) / nm + 63) / 64 * 64;
+      subs.push_back({a, head, true});
+      for (size_t x = a + head; x < pe - tail; x += each) subs.push_back({x, std::min(each, pe - tail - x), false});
+      subs.push_back({pe - tail, tail, false});
+      continue;
+    }
     // near-equal slices (multiples of 64), as many as the pool holds sub-slice lengths, rounded: a pool of 1.05 sub-slices is
     // one launch, not a full one plus a sliver whose launch latency and replay would sit on the critical path
     const size_t len = pe - a, ns = std::max<size_t>(1, (len + sub / 2) / sub);
@@ -1221,7 +1233,8 @@ static int run_subslices(uvaia_gpu_ctx *c, const std::vector<SubSlice> &subs, in
     const int nqt = (c->act_q1 + 15) / 16 - c->act_q0 / 16;
     const size_t waves = ns ? (size_t)nqt * ((subs[0].n + 63) / 64) : 0;
     const char *es = getenv("UVAIA_GPU_SCAN_STREAMS");
-    c->scan_nstreams = es ? std::min(3, std::max(1, atoi(es))) : (waves && waves < 30000 ? 3 : 1);
+    // (a single query tile: the scan is bound by HBM, launches next to each other only slow each other down)
+    c->scan_nstreams = es ? std::min(3, std::max(1, atoi(es))) : (waves && waves < 30000 && nqt >= 4 ? 3 : 1);
   }
   for (size_t i = 0; i < ns; i++) {
     const bool serial_ = c->serial;

@@ -64,6 +64,23 @@ typedef struct {
  * max_incompatible = nchar (src/nearest.c:375,387), plus device buffers for batches of up to max_pool references.
  * device: HIP device index (-1 = current). */
 int uvaia_gpu_open (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool);
+
+/* The same with tuning.  Every field 0 = the library's own choice; the values change speed, never results (the library reads no
+ * environment variables). */
+enum { UVAIA_GPU_SCAN_AUTO = 0,        /* by query count: packed planes up to 16 queries, column-compressed above */
+       UVAIA_GPU_SCAN_PACKED = 1,      /* two-counter scan straight over the packed planes (nothing derived per query set) */
+       UVAIA_GPU_SCAN_COMPRESSED = 2,  /* column-compressed scan over planes derived for the query set */
+       UVAIA_GPU_SCAN_WIDE = 3 };      /* four 32-bit counters per pair (what alignments above 49 000 columns get) */
+typedef struct {
+  size_t subslice_refs;        /* resident search: references per scan launch (pools are cut into slices of about this length; >= 64) */
+  int rare_max;                /* a polymorphic column counts as "rare" when all but at most this many queries carry the same base; -1 = no rare columns */
+  int scan;                    /* UVAIA_GPU_SCAN_* */
+  int serial;                  /* 1 = no overlap between the rebuild of the derived planes, the scans and the replays (isolated kernel timings) */
+  int scan_tiles_per_wave;     /* column-compressed scan: 1 or 2 tiles of 64 references per wave (default 2) */
+  int scan_waves_per_block;    /* column-compressed scan: 4 or 8 waves share a super-tile of 64 queries (default 8) */
+  int reserved[8];             /* zero */
+} uvaia_gpu_tuning;
+int uvaia_gpu_open_tuned (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning /* may be NULL */);
 void uvaia_gpu_close (uvaia_gpu_ctx *ctx);
 const char *uvaia_gpu_last_error (const uvaia_gpu_ctx *ctx);   /* ctx may be NULL: error of the last failed open */
 
@@ -158,7 +175,7 @@ int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, d
 /* counters of the ordered replay since the last reset: out[0] = admissions into heaps, out[1] = pairs whose remaining
  * counters were evaluated on demand, out[2] = of those, evaluated by a dense rescan (ambiguity lists overflowed) */
 int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int reset);
-/* tuning knob: queries held per pass of the scan kernel (8, 16 or 32); 0 = default */
+/* tuning knob: queries held per pass of the packed-plane and four-counter scans (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
 /* ---- query shards: several GPUs, each holding the whole database and the heaps of a contiguous range of the queries.  The
  * per-query machines of src/nearest.c:435-510 are independent given the column classes of the WHOLE query set (which the context
@@ -247,8 +264,8 @@ int    uvaia_gpu_db_append_packed (uvaia_gpu_ctx *ctx, const void *planes, const
 /* bytes the pair scan reads per reference (the default scan reads planes derived from the packed record for this query set) */
 size_t uvaia_gpu_scan_bytes_per_ref (const uvaia_gpu_ctx *ctx);
 /* the pair scan of this context: 2 = column-compressed scan over planes derived for the query set (default above 16 queries),
- * 0 = two-counter scan straight over the packed planes (default up to 16 queries: nothing is derived), 1 = its LDS-broadcast
- * variant, -1 = four-counter scan (alignments above 49 000 columns) */
+ * 0 = two-counter scan straight over the packed planes (default up to 16 queries: nothing is derived), -1 = four-counter scan
+ * (alignments above 49 000 columns) */
 int uvaia_gpu_scan_variant (const uvaia_gpu_ctx *ctx);
 /* bytes per reference uvaia_gpu_db_rederive writes (the planes that depend on the query set; the appends also write the
  * valid-site plane, which does not) */

@@ -16,8 +16,8 @@ def _names(n, p="r"):
     return ["%s%d" % (p, i) for i in range(n)]
 
 
-def _gpu_search(q, refs, pool, nbest, non_n=None):
-    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool) as eng:
+def _gpu_search(q, refs, pool, nbest, non_n=None, tuning=None):
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool, tuning=tuning) as eng:
         entered = []
         for a in range(0, len(refs), pool):
             nn = None if non_n is None else non_n[a:a + pool]
@@ -217,18 +217,18 @@ def test_query_shards_equal_one_context(synth, acgt, gappy):
             e.close()
 
 
-@pytest.mark.parametrize("rare_max", ["1", "3", "40"])
+@pytest.mark.parametrize("rare_max", [1, 3, 40])
 @pytest.mark.parametrize("acgt,trim", [(False, 0), (True, 0), (False, 230), (True, 230)])
-def test_rare_column_path_matches_oracle(synth, monkeypatch, acgt, trim, rare_max):
+def test_rare_column_path_matches_oracle(synth, acgt, trim, rare_max):
     """Columns where all but a few queries carry the same base are scanned as constant columns plus sparse items (and, with
     --acgt, dist_unique takes its rare-column part on demand).  The engine only does that for >= 64 queries; forced here on the
     40-query set, from 'singletons only' to 'every polymorphic column is rare'.  Streaming and resident paths, bundled data too."""
-    monkeypatch.setenv("UVAIA_GPU_RARE_MAX", rare_max)
+    tuning = {"rare_max": rare_max}
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"), acgt=acgt, trim=trim)
-    _assert_same_search(q, refs, 100, 7)
-    rows_s, T_s, ent_s = _gpu_search(q, refs, 100, 7)
-    with capi.Engine.from_query(q, nbest=7, max_pool=512) as eng:
+    _assert_same_search(q, refs, 100, 7, tuning=tuning)
+    rows_s, T_s, ent_s = _gpu_search(q, refs, 100, 7, tuning=tuning)
+    with capi.Engine.from_query(q, nbest=7, max_pool=512, tuning=tuning) as eng:
         eng.db_append(refs)
         ent = eng.search_resident(100)
         n, T, sc, od = eng.drain()
@@ -236,13 +236,12 @@ def test_rare_column_path_matches_oracle(synth, monkeypatch, acgt, trim, rare_ma
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-def test_rare_column_path_on_bundled_alignment(bundled_db, monkeypatch, acgt):
-    monkeypatch.setenv("UVAIA_GPU_RARE_MAX", "2")
+def test_rare_column_path_on_bundled_alignment(bundled_db, acgt):
     names, seqs = bundled_db
     by = dict(zip(names, seqs))
     qn = F.sample_names_1k()[:24]
     q = O.Query([by[n] for n in qn], qn, acgt=acgt)
-    _assert_same_search(q, seqs[:1500], 512, 5)
+    _assert_same_search(q, seqs[:1500], 512, 5, tuning={"rare_max": 2, "scan": "compressed"})
 
 
 @pytest.mark.parametrize("nchar,nq,nref,seed", [(777, 80, 500, 5), (129, 70, 300, 6), (2047, 130, 400, 7)])
@@ -258,36 +257,32 @@ def test_odd_shapes_with_enough_queries_for_every_path(acgt, nchar, nq, nref, se
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-def test_separate_derive_kernels_agree_and_rederive_is_idempotent(acgt, monkeypatch):
-    """The planes the scan reads are built by one fused kernel (default) or by the three kernels it replaced
-    (UVAIA_GPU_DERIVE_SPLIT=1): same heaps either way, and rebuilding them on a resident database changes nothing."""
+@pytest.mark.parametrize("tuning", [None, {"scan_tiles_per_wave": 1}, {"scan_waves_per_block": 4}, {"scan_tiles_per_wave": 1, "scan_waves_per_block": 4}])
+def test_rederive_is_idempotent_and_scan_shapes_agree(acgt, tuning):
+    """Rebuilding the planes the scan reads on a resident database changes nothing; the block shapes of the column-compressed scan
+    (one or two tiles of references per wave, four or eight waves per super-tile of queries) give the same heaps."""
     refs, root, cols = F.synth_alignment(700, 3001, seed=41)
     qs, _, _ = F.synth_alignment(90, 3001, seed=141, root=root, poly_cols=cols)
     q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
-    out = []
-    for split in (False, True):
-        if split:
-            monkeypatch.setenv("UVAIA_GPU_DERIVE_SPLIT", "1")
-        with capi.Engine.from_query(q, nbest=6, max_pool=256) as eng:
-            eng.db_reserve(len(refs))
-            eng.db_append(refs[:333])
-            eng.db_append(refs[333:])
-            ent = eng.search_resident(200)
-            n, T, sc, od = eng.drain()
-            out.append((capi.finalise_heaps(n, sc, od), list(T), ent.copy()))
-            eng.reset()
-            eng.db_rederive()
-            ent2 = eng.search_resident(200)
-            n, T, sc, od = eng.drain()
-            assert (capi.finalise_heaps(n, sc, od), list(T)) == out[-1][:2] and np.array_equal(ent2, out[-1][2])
-    assert out[0][:2] == out[1][:2] and np.array_equal(out[0][2], out[1][2])
+    with capi.Engine.from_query(q, nbest=6, max_pool=256, tuning=tuning) as eng:
+        eng.db_reserve(len(refs))
+        eng.db_append(refs[:333])
+        eng.db_append(refs[333:])
+        ent = eng.search_resident(200)
+        n, T, sc, od = eng.drain()
+        out = (capi.finalise_heaps(n, sc, od), list(T), ent.copy())
+        eng.reset()
+        eng.db_rederive()
+        ent2 = eng.search_resident(200)
+        n, T, sc, od = eng.drain()
+        assert (capi.finalise_heaps(n, sc, od), list(T)) == out[:2] and np.array_equal(ent2, out[2])
     gold = O.search(q, refs, _names(len(refs)), pool=200, nbest=6, ambig_r=1.0)
-    assert out[0][0] == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows] and out[0][1] == gold.final_T
+    assert out[0] == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows] and out[1] == gold.final_T
 
 
 @pytest.mark.parametrize("acgt", [False, True])
 @pytest.mark.parametrize("nq", [5, 16])
-def test_small_query_sets_on_either_scan(monkeypatch, acgt, nq):
+def test_small_query_sets_on_either_scan(acgt, nq):
     """Up to 16 queries the engine scans the packed planes directly (two-counter kernels with tile bounds); the column-compressed
     scan can be forced and must give the same heaps.  Both against the oracle, streamed and resident."""
     refs, root, cols = F.synth_alignment(900, 2100, seed=51)
@@ -296,8 +291,7 @@ def test_small_query_sets_on_either_scan(monkeypatch, acgt, nq):
     with capi.Engine.from_query(q, nbest=4, max_pool=128) as eng:
         assert eng.scan_variant() == 0
     _assert_same_search(q, refs, 128, 4)
-    monkeypatch.setenv("UVAIA_GPU_SCAN", "compressed")
-    with capi.Engine.from_query(q, nbest=4, max_pool=128) as eng:
+    with capi.Engine.from_query(q, nbest=4, max_pool=128, tuning={"scan": "compressed"}) as eng:
         assert eng.scan_variant() == 2
         eng.db_append(refs)
         ent = eng.search_resident(128)
@@ -305,7 +299,7 @@ def test_small_query_sets_on_either_scan(monkeypatch, acgt, nq):
     gold = O.search(q, refs, _names(len(refs)), pool=128, nbest=4, ambig_r=1.0)
     assert capi.finalise_heaps(n, sc, od) == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows]
     assert list(T) == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)
-    _assert_same_search(q, refs, 128, 4)
+    _assert_same_search(q, refs, 128, 4, tuning={"scan": "compressed"})
 
 
 def test_long_alignments_take_the_wide_counter_scan():
@@ -318,13 +312,11 @@ def test_long_alignments_take_the_wide_counter_scan():
         _assert_same_search(O.Query(qs, _names(len(qs), "q"), acgt=acgt), refs, 64, 4)
 
 
-@pytest.mark.parametrize("variant", ["sgpr", "lds"])
 @pytest.mark.parametrize("acgt", [False, True])
-def test_earlier_scan_variants_still_agree(synth, monkeypatch, variant, acgt):
-    """UVAIA_GPU_SCAN=sgpr|lds: the two-counter scans of the kernel history stay usable for A/B runs."""
-    monkeypatch.setenv("UVAIA_GPU_SCAN", variant)
+def test_packed_plane_scan_with_many_query_tiles(synth, acgt):
+    """tuning.scan = packed: the two-counter scan over the packed planes (what up to 16 queries get) on 40 queries = three query tiles"""
     refs, qs = synth
-    _assert_same_search(O.Query(qs, _names(len(qs), "q"), acgt=acgt), refs[:400], 100, 6)
+    _assert_same_search(O.Query(qs, _names(len(qs), "q"), acgt=acgt), refs[:400], 100, 6, tuning={"scan": "packed"})
 
 
 def test_query_tile_sizes_agree(synth):
@@ -426,12 +418,11 @@ def test_heavily_ambiguous_sequences_use_the_dense_rescan():
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-def test_four_counter_path_still_agrees(synth, acgt, monkeypatch):
-    """UVAIA_GPU_FULLSCAN=1 selects the four-counter scan + replay (kept for A/B measurements)."""
-    monkeypatch.setenv("UVAIA_GPU_FULLSCAN", "1")
+def test_four_counter_path_still_agrees(synth, acgt):
+    """tuning.scan = wide selects the four-counter scan + its replay (what alignments above 49 000 columns get)."""
     refs, qs = synth
     q = O.Query(qs, _names(len(qs), "q"), acgt=acgt)
-    _assert_same_search(q, refs, 96, 9)
+    _assert_same_search(q, refs, 96, 9, tuning={"scan": "wide"})
 
 
 @pytest.mark.parametrize("acgt", [False, True])
@@ -514,7 +505,7 @@ def test_host_non_n_does_not_leak_into_counts(synth):
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-def test_benchmark_shaped_data_push_and_resident(acgt, monkeypatch):
+def test_benchmark_shaped_data_push_and_resident(acgt):
     """Generator data at full genome length with k = 100: dozens of tiles per query, tolerances that rise and fall, and a
     resident search cut into sub-slices (scan several counter buffers ahead of the replay).  Both paths must equal the oracle."""
     from uvaia_amd import hostlib
@@ -531,9 +522,8 @@ def test_benchmark_shaped_data_push_and_resident(acgt, monkeypatch):
         n, T, sc, od = e.drain()
         assert capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T
         assert list(np.nonzero(ent)[0]) == list(gold.saved)
-    monkeypatch.setenv("UVAIA_GPU_SUBSLICE", "448")      # 6 sub-slices, not tile aligned, ring of counter buffers wraps
-    monkeypatch.setenv("UVAIA_GPU_SUBSLICE_MINQ", "1")
-    with pq.open_engine(nbest=100, max_pool=2600) as e:
+    # 6 sub-slices, not tile aligned, ring of counter buffers wraps
+    with pq.open_engine(nbest=100, max_pool=2600, tuning={"subslice_refs": 448}) as e:
         e.db_reserve(len(refs))
         e.db_append(refs[:1000]); e.db_append(refs[1000:])
         for _ in range(2):

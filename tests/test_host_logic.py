@@ -60,10 +60,11 @@ def test_query_preparation_with_redundancy(acgt, keep, ball):
         assert a.ntax < len(qs)
 
 
-def test_host_pruning_loop_stays_available_for_large_sets(monkeypatch):
-    """From 512 queries on the pair test of the pruning runs on the device (tests/test_query_prep_gpu.py); UVAIA_PRUNE=host keeps
-    the serial host loop, which is what this CPU test can run: same survivors as the oracle."""
-    monkeypatch.setenv("UVAIA_PRUNE", "host")
+def test_host_pruning_loop_stays_available_for_large_sets(request):
+    """From 512 queries on the pair test of the pruning runs on the device (tests/test_query_prep_gpu.py); uvaia_set_prune_mode(host)
+    keeps the serial host loop, which is what this CPU test can run: same survivors as the oracle."""
+    H.set_prune_mode("host")
+    request.addfinalizer(lambda: H.set_prune_mode("auto"))
     base, root, cols = F.synth_alignment(270, 400, seed=33, p_snp=0.01)
     qs = []
     for i, s in enumerate(base):

@@ -56,12 +56,15 @@ def test_agreement_matrix(acgt, trim):
 
 @pytest.mark.parametrize("acgt", [False, True])
 @pytest.mark.parametrize("keep,ball", [(True, False), (False, True), (True, True)])
-def test_pruning_on_device_equals_host_and_oracle(monkeypatch, acgt, keep, ball):
+def test_pruning_on_device_equals_host_and_oracle(acgt, keep, ball):
     qs, names = _redundant_set(40, 1800, seed=8)
-    monkeypatch.setenv("UVAIA_PRUNE", "host")
-    host = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
-    monkeypatch.setenv("UVAIA_PRUNE", "device")
-    dev = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    try:
+        H.set_prune_mode("host")
+        host = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+        H.set_prune_mode("device")
+        dev = H.PreparedQuery(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
+    finally:
+        H.set_prune_mode("auto")
     gold = O.Query(qs, names, acgt=acgt, keep_resolved=keep, is_ball=ball, dist=3)
     assert dev.names == host.names == gold.names and dev.seqs == gold.seqs
     assert dev.ntax < len(qs)

@@ -74,13 +74,12 @@ def test_config1_regime_default_switches_equal_oracle(config1_sample):
         assert admitted > 100 * 1000                         # heaps fill and keep turning over: the regime of the benchmark
 
 
-def test_config1_regime_sub_slices_equal_oracle(config1_sample, monkeypatch):
+def test_config1_regime_sub_slices_equal_oracle(config1_sample):
     """(a) the same search cut into five sub-slices that are not tile aligned (the 100 000-reference benchmark run cuts its pools
     into three): scans run ahead of the replay in the ring of counter buffers, which wraps."""
     gen, qs, qn, refs, oq, gold = config1_sample
-    monkeypatch.setenv("UVAIA_GPU_SUBSLICE", "1700")
     pq = hostlib.PreparedQuery(qs, qn)
-    with pq.open_engine(nbest=100, max_pool=8000) as eng:
+    with pq.open_engine(nbest=100, max_pool=8000, tuning={"subslice_refs": 1700}) as eng:
         _load(eng, gen, 0, len(refs))
         rows, T, ent = _timed_step(eng, 8000)
         assert rows == _want(gold, oq.ntax) and T == gold.final_T
@@ -127,7 +126,7 @@ def _heap_pairs(rows):
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt, monkeypatch):
+def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt):
     """(c) 1 000 queries x 100 000 references (BASELINE config[1]; also with --acgt), pool 65 536: the timed step (rederive on its
     own stream overlapping three sub-slice scans), the same step with every launch serialised, and the streaming push path must
     leave identical heaps, tolerances and dump flags; and the six scores of heap entries are the oracle's untruncated pair scores
@@ -142,11 +141,9 @@ def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt, mon
         rows, T, ent = _timed_step(eng, pool)
         rows2, T2, ent2 = _timed_step(eng, pool)
         assert rows2 == rows and T2 == T and np.array_equal(ent, ent2)
-    monkeypatch.setenv("UVAIA_GPU_SERIAL", "1")
-    with pq.open_engine(nbest=100, max_pool=pool) as eng:
+    with pq.open_engine(nbest=100, max_pool=pool, tuning={"serial": 1}) as eng:
         _load(eng, gen, 0, n_ref)
         rows_s, T_s, ent_s = _timed_step(eng, pool)
-    monkeypatch.delenv("UVAIA_GPU_SERIAL")
     assert rows_s == rows and T_s == T and np.array_equal(ent_s, ent)
     with pq.open_engine(nbest=100, max_pool=pool) as eng:              # streaming: two pools of raw characters
         ent_p = []

@@ -20,7 +20,7 @@ for nq in sizes:
     for mode in ("device", "host"):
         if mode == "host" and nq > 3000:
             continue                      # minutes
-        os.environ["UVAIA_PRUNE"] = mode
+        hostlib.set_prune_mode(mode)
         t0 = time.time()
         pq = hostlib.PreparedQuery(qseqs, names, keep_resolved=True)
         row["prepare_with_pruning_%s_s" % mode] = round(time.time() - t0, 2)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle campaign (run on the GPU box): shapes, modes and engine switches drawn at random; every search must
+"""Randomised GPU-vs-oracle campaign (run on the GPU box): shapes, modes and tuning values drawn at random; every search must
 give the oracle's heaps, tolerances and dump flags, streamed and resident.  python tools/stress_parity.py [--n 40] [--seed 1]"""
 import argparse
 import os
@@ -24,15 +24,9 @@ def one(rng, k):
     trim = rng.choice([0, 0, 7, min(230, nchar // 4)])
     nbest = rng.choice([1, 2, 5, 13, 40])
     pool = rng.choice([64, 97, 333, 1000, nref])
-    env = {"UVAIA_GPU_RARE_MAX": rng.choice([None, "0", "1", "3", "50"]), "UVAIA_GPU_SCAN_QBLOCK": rng.choice([None, "0", "1"]),
-           "UVAIA_GPU_SUBSLICE": rng.choice([None, "64", "256"]), "UVAIA_GPU_SUBSLICE_MINQ": rng.choice([None, "1"]),
-           "UVAIA_GPU_DERIVE_SPLIT": rng.choice([None, None, None, "1"]),
-           "UVAIA_GPU_SCAN": rng.choice([None, None, "compressed"])}          # <= 16 queries scan the packed planes unless forced
-    for key, v in env.items():
-        if v is None:
-            os.environ.pop(key, None)
-        else:
-            os.environ[key] = v
+    tuning = {"rare_max": rng.choice([0, -1, 1, 3, 50]), "subslice_refs": rng.choice([0, 64, 256]),
+              "scan_tiles_per_wave": rng.choice([0, 1, 2]), "scan_waves_per_block": rng.choice([0, 4, 8]),
+              "scan": rng.choice(["auto", "auto", "compressed"])}          # <= 16 queries scan the packed planes unless told otherwise
     p_snp = rng.choice([0.002, 0.006, 0.02])
     refs, root, cols = F.synth_alignment(nref, nchar, seed=1000 + k, p_snp=p_snp)
     qs, _, _ = F.synth_alignment(nq, nchar, seed=5000 + k, root=root, poly_cols=cols, p_snp=p_snp)
@@ -42,18 +36,18 @@ def one(rng, k):
             a = (i * 37) % max(1, nchar - 20)
             s[a:a + 20] = b"N" * len(s[a:a + 20])
         qs = [bytes(s) for s in qs]
-    desc = dict(nchar=nchar, nq=nq, nref=nref, acgt=acgt, trim=trim, nbest=nbest, pool=pool, p_snp=p_snp, **{k_: v for k_, v in env.items() if v is not None})
+    desc = dict(nchar=nchar, nq=nq, nref=nref, acgt=acgt, trim=trim, nbest=nbest, pool=pool, p_snp=p_snp, **{k_: v for k_, v in tuning.items() if v not in (0, "auto")})
     q = O.Query(qs, ["q%d" % i for i in range(nq)], acgt=acgt, trim=trim, ambig_q=1.0)
     if q.ntax < 1:
         return desc, True
     gold = O.search(q, refs, ["r%d" % i for i in range(nref)], pool=pool, nbest=nbest, ambig_r=1.0)
     want = [[(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(q.ntax)]
     ok = True
-    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool) as eng:           # streamed
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool, tuning=tuning) as eng:           # streamed
         ent = [eng.push(refs[a:a + pool]) for a in range(0, nref, pool)]
         n, T, sc, od = eng.drain()
         ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(np.concatenate(ent))[0]) == list(gold.saved)
-    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool) as eng:           # resident
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool, tuning=tuning) as eng:           # resident
         eng.db_append(refs)
         e2 = eng.search_resident(pool)
         n, T, sc, od = eng.drain()

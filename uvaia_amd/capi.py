@@ -12,7 +12,7 @@ NSCORE = 6
 
 # every symbol include/uvaia_gpu.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "uvaia_gpu_open", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
+    "uvaia_gpu_open", "uvaia_gpu_open_tuned", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
     "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_agree_on_polymorphic",
     "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
@@ -32,6 +32,24 @@ class GpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("uvaia_gpu error %d: %s" % (code, msg))
         self.code = code
+
+
+class Tuning(C.Structure):
+    """uvaia_gpu_tuning: optional knobs of uvaia_gpu_open_tuned (0 = the library's choice); they change speed, never results."""
+    _fields_ = [("subslice_refs", C.c_size_t), ("rare_max", C.c_int), ("scan", C.c_int), ("serial", C.c_int),
+                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("reserved", C.c_int * 8)]
+
+    SCAN = {"auto": 0, "packed": 1, "compressed": 2, "wide": 3}
+
+    @classmethod
+    def make(cls, tuning):
+        """None, a Tuning, or a dict such as {"scan": "compressed", "subslice_refs": 448, "serial": 1}"""
+        if tuning is None or isinstance(tuning, cls):
+            return tuning
+        t = cls()
+        for k, v in tuning.items():
+            setattr(t, k, cls.SCAN[v] if k == "scan" and isinstance(v, str) else int(v))
+        return t
 
 
 class _Query(C.Structure):
@@ -74,6 +92,7 @@ def load_library():
     pi = C.POINTER(C.c_int)
     sig = {
         "uvaia_gpu_open": (C.c_int, [C.POINTER(vp), C.POINTER(_Query), C.c_int, C.c_int, C.c_size_t]),
+        "uvaia_gpu_open_tuned": (C.c_int, [C.POINTER(vp), C.POINTER(_Query), C.c_int, C.c_int, C.c_size_t, C.POINTER(Tuning)]),
         "uvaia_gpu_close": (None, [vp]),
         "uvaia_gpu_last_error": (C.c_char_p, [vp]),
         "uvaia_gpu_push": (C.c_int, [vp, pp, pi, C.c_int, C.c_int64, C.POINTER(C.c_uint8)]),
@@ -168,7 +187,7 @@ def _int_ptr(a):
 class Engine:
     """One GPU context over a prepared query set (fields of struct query_struct, src/fastaseq.h:41-48)."""
 
-    def __init__(self, seqs, consensus, idx_c, idx_m, idx, trim=0, acgt=False, nbest=100, max_pool=4096, device=-1):
+    def __init__(self, seqs, consensus, idx_c, idx_m, idx, trim=0, acgt=False, nbest=100, max_pool=4096, device=-1, tuning=None):
         self.L = load_library()
         self.nq, self.nchar = len(seqs), len(consensus)
         self._keep = [_cstrs(seqs), consensus,
@@ -178,7 +197,8 @@ class Engine:
         q = _Query(self.nq, self.nchar, self._keep[0], consensus, self._keep[2], self._keep[3], self._keep[4],
                    len(idx_c), len(idx_m), len(idx), int(trim), int(bool(acgt)))
         self.ctx = C.c_void_p()
-        rc = self.L.uvaia_gpu_open(C.byref(self.ctx), C.byref(q), int(nbest), int(device), int(max_pool))
+        tn = Tuning.make(tuning)
+        rc = self.L.uvaia_gpu_open_tuned(C.byref(self.ctx), C.byref(q), int(nbest), int(device), int(max_pool), C.byref(tn) if tn is not None else None)
         if rc != 0:
             msg = self.L.uvaia_gpu_last_error(None)
             self.ctx = None

@@ -28,6 +28,13 @@ uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int dev
 }
 
 int
+uvaia_gpu_open_query_tuned (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning)
+{
+  uvaia_gpu_query q = as_gpu_query (query);
+  return uvaia_gpu_open_tuned (ctx, &q, heap_size, device, max_pool, tuning);
+}
+
+int
 uvaia_gpu_group_open_query (uvaia_gpu_group **group, query_t query, int heap_size, const int *devices, int n_devices, size_t max_pool, size_t piece_refs)
 {
   uvaia_gpu_query q = as_gpu_query (query);

@@ -15,6 +15,7 @@ extern "C" {
 
 /* uvaia_gpu_open() from a prepared query_t (after create_query_indices / reorder_query_structure) */
 int uvaia_gpu_open_query (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int device, size_t max_pool);
+int uvaia_gpu_open_query_tuned (uvaia_gpu_ctx **ctx, query_t query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning);
 
 /* Fills n_query host heaps (made with new_heap_t(heap_size)) from the device heaps, slot for slot, including
  * max_incompatible; name_of(ordinal, user) must return the reference name for an ordinal (it is strdup()ed, as

@@ -14,7 +14,7 @@ exclude_redundant_query_sequences_device (query_t query, int keep_resolved)
   const size_t batch = n < 2048 ? (size_t) n : 2048;
   uvaia_gpu_ctx *gpu = NULL;
   if (uvaia_gpu_open_query (&gpu, query, 1, -1, batch))
-    biomcmc_error ("pruning redundant queries on the GPU: %s (UVAIA_PRUNE=host runs the serial host loop instead)", uvaia_gpu_last_error (NULL));
+    biomcmc_error ("pruning redundant queries on the GPU: %s (uvaia_set_prune_mode(1) runs the serial host loop instead)", uvaia_gpu_last_error (NULL));
   unsigned char *agree = (unsigned char *) biomcmc_malloc ((size_t) n * n);
   for (int a = 0; a < n; a += (int) batch) {
     const int m = n - a < (int) batch ? n - a : (int) batch;
@@ -27,14 +27,14 @@ exclude_redundant_query_sequences_device (query_t query, int keep_resolved)
 }
 
 /* the pair test costs O(Q^2 x polymorphic columns) on one host thread (14 s at 3 000 queries): from this many queries on it
-   runs on the device.  UVAIA_PRUNE=host|device overrides. */
+   runs on the device.  uvaia_set_prune_mode() overrides (tests). */
 #define UVAIA_PRUNE_DEVICE_FROM 512
+static int prune_mode = 0;     /* 0 = by query count, 1 = host, 2 = device */
+void uvaia_set_prune_mode (int mode) { prune_mode = (mode == 1 || mode == 2) ? mode : 0; }
 static int
 prune_on_device (int ntax)
 {
-  const char *e = getenv ("UVAIA_PRUNE");
-  if (e && !strcmp (e, "host")) return 0;
-  if (e && !strcmp (e, "device")) return 1;
+  if (prune_mode) return prune_mode == 2;
   return ntax >= UVAIA_PRUNE_DEVICE_FROM;
 }
 

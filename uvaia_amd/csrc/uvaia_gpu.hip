@@ -94,10 +94,7 @@ struct uvaia_gpu_ctx {
   // query side
   uint32_t *d_qp = nullptr;      // [nq_pad][W4][4][NQ]   full-information query planes
   uint32_t *d_qp2 = nullptr;     // [nq_pad][W4][4][4]    (lo, hi, isACGT, valid) for the two-counter scan (default mode)
-  uint4 *d_qv = nullptr;         // [nq_pad/16][W4pad][16][4]  the same planes laid out for LDS staging (scan2v_kernel)
-  int W4pad = 0;
-  int scan_variant = 2;          // 2 = column-compressed scan3_kernel (default); 0 = scalar-operand scan2_*_kernel, 1 = LDS-broadcast
-                                 // scan2v_kernel (UVAIA_GPU_SCAN=sgpr|lds), kept for A/B measurements
+  int scan_variant = 2;          // 2 = column-compressed scan3_kernel (default above 16 queries); 0 = scan2_*_kernel over the packed planes
   // column-compressed scan: classes of the alignment columns for this query set, compressed/dirty query planes, derived reference planes
   uint32_t *d_cls = nullptr;     // [W4*4][4]  cL, cH, constMask, polyMask
   uint32_t *d_qpl = nullptr;     // [nq_pad][NP4][L,H,I,-][4]   compressed polymorphic columns of the queries
@@ -113,15 +110,11 @@ struct uvaia_gpu_ctx {
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
-  int scan_qblock = -1;          // UVAIA_GPU_SCAN_QBLOCK: block = 4 query tiles x 1 reference tile (1) or 1 x 4 (0); default by active query tiles
-  bool serial = false;           // UVAIA_GPU_SERIAL: no scan/replay overlap (to time the kernels in isolation)
-  int subslice_minq = 256;       // sub-slicing of pools only from this many active queries (UVAIA_GPU_SUBSLICE_MINQ)
-  int scan_lds_pad = 0;          // extra (unused) LDS per scan block: caps the scan's blocks per CU so that replay waves find free slots
+  bool serial = false;           // tuning.serial: no scan/replay overlap (to time the kernels in isolation)
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
-  int replay_prio = 1;           // replay waves raise their issue priority (UVAIA_GPU_REPLAY_PRIO=0 to compare)
+  int replay_prio = 1;           // replay waves raise their issue priority
   int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)
   int scan_NW = 8;               // waves per block of scan3_kernel = shares a super-tile's records are cut into
-  int scan_QS = 64;              // queries of a super-tile of scan3_kernel (64 or 128; 128 goes with 16 waves per block)
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
   uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
@@ -130,7 +123,7 @@ struct uvaia_gpu_ctx {
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
   int2 *d_cnt2 = nullptr;        // [nq_pad][pool_pad] two-counter scan output
   unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
-  bool fullscan = false;         // UVAIA_GPU_FULLSCAN=1: four-counter scan + replay over it (kept for A/B and tests)
+  bool fullscan = false;         // four-counter scan + the replay over it (alignments above 49 000 columns; tuning.scan = UVAIA_GPU_SCAN_WIDE)
   size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
   uint32_t *d_cpm = nullptr;     // consensus restricted to idx_m (radius search)
@@ -300,33 +293,17 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
       tile_first = dtile_of(c, tile_first);
     }
     const int *tote = (is_db ? c->d_db_tote : c->d_batch_tote) + tile_first * 64;
-    const int QS = c->scan_QS;
+    constexpr int QS = 64;                       // queries of a super-tile of scan3_kernel
     if (c->act_q0 % QS) return fail(c, UVAIA_GPU_ESTATE, "the scan works on super-tiles of %d queries: active queries start at a multiple of that", QS);
     const int st_first = c->act_q0 / QS, n_st = (c->act_q1 + QS - 1) / QS - st_first;
     const int R = c->scan_R;
     dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
-#define SCAN3_LAUNCH(NWW, A, RR, QQ, AB) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR, QQ, AB>), grid3, dim3(64 * NWW), c->scan_lds_pad, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
-#define SCAN3_NW(A, RR) { if (QS == 128) SCAN3_LAUNCH(16, A, RR, 128, 0); else if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR, 64, 0); else SCAN3_LAUNCH(4, A, RR, 64, 0); }
-    static const int abl = getenv("UVAIA_GPU_SCAN_ABLATE") ? atoi(getenv("UVAIA_GPU_SCAN_ABLATE")) : 0;     // TEMPORARY experiment: results invalid
-    if (R == 2 && abl && !c->acgt && c->scan_NW == 8) {
-      if (abl == 1) SCAN3_LAUNCH(8, false, 2, 64, 1); else if (abl == 2) SCAN3_LAUNCH(8, false, 2, 64, 2); else SCAN3_LAUNCH(8, false, 2, 64, 3);
-    } else
+#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
+#define SCAN3_NW(A, RR) { if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR); else SCAN3_LAUNCH(4, A, RR); }
     if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
     else        { if (c->acgt) SCAN3_NW(true, 1) else SCAN3_NW(false, 1) }
 #undef SCAN3_NW
 #undef SCAN3_LAUNCH
-    HIPCHK(c, hipGetLastError());
-    if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
-    consensus_rt();
-    HIPCHK(c, hipGetLastError());
-    return 0;
-  }
-  if (c->scan_variant == 1) {
-    constexpr int QTV = 16, RV = 2;
-    const int nqtv = (c->nq + QTV - 1) / QTV;
-    dim3 gridv(scan_grid_size(nqtv, (n_tiles + 4 * RV - 1) / (4 * RV)));
-    if (c->acgt) hipLaunchKernelGGL((scan2v_kernel<QTV, RV, true>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
-    else         hipLaunchKernelGGL((scan2v_kernel<QTV, RV, false>), gridv, block, 0, stream, tiles, tile_first, n_tiles, c->W4, c->W4pad, c->d_qv, out, ppad, nqtv);
     HIPCHK(c, hipGetLastError());
     if (c->profile) { HIPCHK(c, hipEventRecord(ev_.b, stream)); ev_.bytes = bytes; c->evts.push_back(ev_); }
     consensus_rt();
@@ -489,7 +466,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   void *dev[] = {c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
-                 c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qv, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+                 c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -505,7 +482,16 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
 }
 
 int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size, int device, size_t max_pool)
+{ return uvaia_gpu_open_tuned(out, q, heap_size, device, max_pool, nullptr); }
+
+int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tune)
 {
+  uvaia_gpu_tuning tn;
+  memset(&tn, 0, sizeof tn);
+  if (tune) tn = *tune;
+  if (tn.scan < 0 || tn.scan > UVAIA_GPU_SCAN_WIDE || (tn.scan_tiles_per_wave != 0 && tn.scan_tiles_per_wave != 1 && tn.scan_tiles_per_wave != 2) ||
+      (tn.scan_waves_per_block != 0 && tn.scan_waves_per_block != 4 && tn.scan_waves_per_block != 8) || (tn.subslice_refs != 0 && tn.subslice_refs < 64))
+    return fail(nullptr, UVAIA_GPU_EINVAL, "bad tuning values");
   if (!out) return fail(nullptr, UVAIA_GPU_EINVAL, "ctx is NULL");
   *out = nullptr;
   if (!q || q->n_query < 1 || q->nchar < 1 || !q->seq || !q->consensus) return fail(nullptr, UVAIA_GPU_EINVAL, "empty or incomplete query set");
@@ -524,15 +510,14 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   c->W = (c->nchar + 31) / 32; c->W4 = (c->W + 3) / 4;
   c->k = heap_size < 2 ? 2 : heap_size;                      // src/min_heap.c:58
   c->qt = c->nq <= 8 ? 8 : 16;
-  const char *env_qt = getenv("UVAIA_GPU_QT");
-  if (env_qt) { int v = atoi(env_qt); if (v == 8 || v == 16 || v == 32) c->qt = v; }
-  const char *env_scan = getenv("UVAIA_GPU_SCAN");
-  if (env_scan) c->scan_variant = (strcmp(env_scan, "lds") == 0) ? 1 : (strcmp(env_scan, "sgpr") == 0) ? 0 : 2;
   // One query tile: the column-compressed scan would move 25 KB per reference (building its planes) to read 1-8 KB; the
   // two-counter scan over the packed planes reads each reference once (15 KB) and needs nothing derived.
-  else if (c->nq <= 16) c->scan_variant = 0;
-  const char *env_full = getenv("UVAIA_GPU_FULLSCAN");
-  c->fullscan = env_full && atoi(env_full) != 0;
+  c->scan_variant = tn.scan == UVAIA_GPU_SCAN_PACKED ? 0 : tn.scan == UVAIA_GPU_SCAN_COMPRESSED ? 2 : (c->nq <= 16 ? 0 : 2);
+  c->fullscan = tn.scan == UVAIA_GPU_SCAN_WIDE;
+  c->serial = tn.serial != 0;
+  if (tn.scan_tiles_per_wave) c->scan_R = tn.scan_tiles_per_wave;
+  if (tn.scan_waves_per_block) c->scan_NW = tn.scan_waves_per_block;
+  if (tn.subslice_refs) { c->subslice = tn.subslice_refs; c->subslice_forced = true; }
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
   // four-counter scan instead (32-bit counts, same results, slower)
   if (c->nchar > 49000) c->fullscan = true;
@@ -550,12 +535,8 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
     c->scan_streams[0] = c->scan_stream;
     for (int i = 1; i < 3; i++) OPENCHK(hipStreamCreateWithPriority(&c->scan_streams[i], hipStreamNonBlocking, prio_least));
     for (int i = 0; i < NBUF; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
-    {   // between the scan (lowest) and the replay (highest): its blocks take the slots scan blocks free, ahead of the next scan blocks
-      const char *ep = getenv("UVAIA_GPU_DERIVE_PRIO");
-      const int mid = (prio_least + prio_greatest) / 2;
-      const int pr = ep ? std::max(prio_greatest, std::min(prio_least, atoi(ep))) : mid;
-      OPENCHK(hipStreamCreateWithPriority(&c->derive_stream, hipStreamNonBlocking, pr));
-    }
+    // between the scan (lowest) and the replay (highest): its blocks take the slots scan blocks free, ahead of the next scan blocks
+    OPENCHK(hipStreamCreateWithPriority(&c->derive_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
   }
   uint8_t code_tab[256]; fill_code_table(code_tab);
   OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
@@ -604,20 +585,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       } });
       OPENCHK(hipMalloc(&c->d_qp2, qp2.size() * 4)); OPENCHK(hipMemcpy(c->d_qp2, qp2.data(), qp2.size() * 4, hipMemcpyHostToDevice));
     }
-    {  // LDS-staging layout: [query tile of 16][w4 (padded to 8)][query in tile][word j] -> uint4 of the four planes
-      c->W4pad = (c->W4 + 7) / 8 * 8;
-      const int ntile = c->nq_pad / 16;
-      std::vector<uint32_t> qvh((size_t)ntile * c->W4pad * 16 * 4 * 4, 0u);
-      parallel_for(c->nq, [&](int i) { for (int w = 0; w < c->W4 * 4; w++) {
-        uint32_t pl[4];
-        if (c->acgt) { const uint32_t *s4 = qp.data() + (size_t)i * row_words + (size_t)w * 4; pl[0] = s4[0]; pl[1] = s4[1]; pl[2] = s4[2]; pl[3] = s4[3]; }
-        else { const uint32_t *s6 = qp.data() + (size_t)i * row_words + (size_t)w * 6; const uint32_t one = s6[5];
-               pl[0] = (s6[1] | s6[3]) & one; pl[1] = (s6[2] | s6[3]) & one; pl[2] = one; pl[3] = s6[4]; }
-        uint32_t *d = qvh.data() + ((((size_t)(i / 16) * c->W4pad + (w >> 2)) * 16 + (i % 16)) * 4 + (w & 3)) * 4;
-        d[0] = pl[0]; d[1] = pl[1]; d[2] = pl[2]; d[3] = pl[3];
-      } });
-      OPENCHK(hipMalloc(&c->d_qv, qvh.size() * 4)); OPENCHK(hipMemcpy(c->d_qv, qvh.data(), qvh.size() * 4, hipMemcpyHostToDevice));
-    }
     {  // column classes and compressed/dirty query planes for scan3_kernel
       const int Wp = c->W4 * 4;
       auto QL = [&](int i, int w, int pl) -> uint32_t {          // (lo, hi, isACGT, valid-or-isACGT) of query i, word w
@@ -642,8 +609,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       // sparse item on the gathered planes of the rare columns.  Dense work remains for the truly polymorphic columns only.
       std::vector<uint32_t> rmask((size_t)Wp, 0u);
       {
-        const char *er = getenv("UVAIA_GPU_RARE_MAX");
-        c->rare_max = er ? atoi(er) : (c->nq < 64 ? 0 : std::min(64, std::max(4, c->nq / 64)));
+        c->rare_max = tn.rare_max > 0 ? tn.rare_max : tn.rare_max < 0 ? 0 : (c->nq < 64 ? 0 : std::min(64, std::max(4, c->nq / 64)));
         if (c->fullscan || c->scan_variant != 2) c->rare_max = 0;
       }
       if (c->rare_max > 0) {
@@ -713,12 +679,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
         for (int t = 0; t < c->nq_pad / 16; t++) { u |= flg[((size_t)t * c->W4 + g) * 2]; uy |= flg[((size_t)t * c->W4 + g) * 2 + 1]; }
         c->need_e_groups += (u & 0xFFFFu) != 0; c->need_v_groups += (u >> 16) != 0; c->need_g_groups += uy != 0;
       }
-      { const char *ep = getenv("UVAIA_GPU_REPLAY_PRIO"); if (ep) c->replay_prio = atoi(ep); }
-      { const char *ep = getenv("UVAIA_GPU_SCAN_LDS_PAD"); if (ep) c->scan_lds_pad = atoi(ep); }
-      { const char *ep = getenv("UVAIA_GPU_REPLAY_LQ"); if (ep) c->replay_lq = atoi(ep); }
-      { const char *ep = getenv("UVAIA_GPU_SUBSLICE_MINQ"); if (ep) c->subslice_minq = atoi(ep); }
-      c->serial = getenv("UVAIA_GPU_SERIAL") != nullptr;
-      { const char *ep = getenv("UVAIA_GPU_SCAN_QBLOCK"); if (ep) c->scan_qblock = atoi(ep); }
       // Next to a running scan (8 blocks x 16.9 KB of LDS per CU) a replay block with the 22 KB query row fits once per CU, without
       // it seven times: with many queries the replay then waits for LDS, not for work (5.48 -> 5.04 ms per config[1] search).
       if (c->replay_lq < 0) c->replay_lq = (c->nq < 256) ? 1 : 0;
@@ -737,11 +697,7 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
       }
       OPENCHK(hipMalloc(&c->d_qpl, qpl.size() * 4)); OPENCHK(hipMemcpy(c->d_qpl, qpl.data(), qpl.size() * 4, hipMemcpyHostToDevice));
       // the item stream of every query tile (layout: see scan3_kernel)
-      { const char *er = getenv("UVAIA_GPU_SCAN_R"); if (er) c->scan_R = atoi(er) == 1 ? 1 : 2; }
-      { const char *er = getenv("UVAIA_GPU_SCAN_NW"); if (er) c->scan_NW = atoi(er) == 4 ? 4 : atoi(er) == 16 ? 16 : 8; }
-      { const char *er = getenv("UVAIA_GPU_SCAN_QS"); if (er) c->scan_QS = atoi(er) == 128 ? 128 : 64; }
-      if (c->scan_QS == 128) c->scan_NW = 16; else if (c->scan_NW == 16) c->scan_NW = 8;
-      const int NWs = c->scan_NW, QS = c->scan_QS;
+      const int NWs = c->scan_NW, QS = 64;
       const uint32_t row_b = 256u * (uint32_t)c->scan_R;      // bytes of a query's counter row in a wave's LDS block: 64 lanes x R tiles x 4
       // one stream per super-tile of 64 queries (scan3_kernel: four waves share the counters and the stream)
       struct Rec { size_t at; uint32_t cost; };
@@ -867,7 +823,6 @@ int uvaia_gpu_open(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap_size,
   OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   OPENCHK(hipMalloc(&c->d_rtb[0], c->pool_pad * sizeof(int4)));
   OPENCHK(hipMemset(c->d_rtb[0], 0, c->pool_pad * sizeof(int4)));
-  { const char *env_sub = getenv("UVAIA_GPU_SUBSLICE"); if (env_sub && atol(env_sub) >= 64) { c->subslice = (size_t)atol(env_sub); c->subslice_forced = true; } }
   if (c->acgt && !c->fullscan && c->scan_variant == 2) OPENCHK(hipMalloc(&c->d_mp[0], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
@@ -1232,9 +1187,8 @@ static int run_subslices(uvaia_gpu_ctx *c, const std::vector<SubSlice> &subs, in
       // launches of consecutive slices overlap (they write different buffers)
     const int nqt = (c->act_q1 + 15) / 16 - c->act_q0 / 16;
     const size_t waves = ns ? (size_t)nqt * ((subs[0].n + 63) / 64) : 0;
-    const char *es = getenv("UVAIA_GPU_SCAN_STREAMS");
     // (a single query tile: the scan is bound by HBM, launches next to each other only slow each other down)
-    c->scan_nstreams = es ? std::min(3, std::max(1, atoi(es))) : (waves && waves < 30000 && nqt >= 4 ? 3 : 1);
+    c->scan_nstreams = (waves && waves < 30000 && nqt >= 4) ? 3 : 1;
   }
   for (size_t i = 0; i < ns; i++) {
     const bool serial_ = c->serial;

@@ -68,6 +68,9 @@ def load_library():
     L.del_query_structure.argtypes = [qp]
     L.uvaia_gpu_open_query.restype = C.c_int
     L.uvaia_gpu_open_query.argtypes = [C.POINTER(C.c_void_p), qp, C.c_int, C.c_int, C.c_size_t]
+    L.uvaia_gpu_open_query_tuned.restype = C.c_int
+    L.uvaia_gpu_open_query_tuned.argtypes = [C.POINTER(C.c_void_p), qp, C.c_int, C.c_int, C.c_size_t, C.POINTER(capi.Tuning)]
+    L.uvaia_set_prune_mode.argtypes = [C.c_int]
     L.new_heap_t.restype = hp
     L.new_heap_t.argtypes = [C.c_int]
     L.del_heap_t.argtypes = [hp]
@@ -118,13 +121,14 @@ class PreparedQuery:
             self.idx_m = np.array([q.idx_m[i] for i in range(q.n_idx_m)], dtype=np.int64)
             self.idx = np.array([q.idx[i] for i in range(q.n_idx)], dtype=np.int64)
 
-    def open_engine(self, nbest=100, max_pool=4096, device=-1):
+    def open_engine(self, nbest=100, max_pool=4096, device=-1, tuning=None):
         """uvaia_gpu_open_query(): an Engine over this query set."""
         eng = capi.Engine.__new__(capi.Engine)
         eng.L = capi.load_library()
         eng.nq, eng.nchar = self.ntax, self.nchar
         eng.ctx = C.c_void_p()
-        rc = self._L.uvaia_gpu_open_query(C.byref(eng.ctx), self.ptr, int(nbest), int(device), int(max_pool))
+        tn = capi.Tuning.make(tuning)
+        rc = self._L.uvaia_gpu_open_query_tuned(C.byref(eng.ctx), self.ptr, int(nbest), int(device), int(max_pool), C.byref(tn) if tn is not None else None)
         if rc != 0:
             msg = eng.L.uvaia_gpu_last_error(None)
             eng.ctx = None
@@ -139,6 +143,11 @@ class PreparedQuery:
             self._L.del_query_structure(self.ptr)
         except Exception:
             pass
+
+
+def set_prune_mode(mode):
+    """where exclude_redundant_query_sequences' pair test runs: "auto" (device from 512 queries), "host", "device" """
+    load_library().uvaia_set_prune_mode({"auto": 0, "host": 1, "device": 2}[mode])
 
 
 class Synth:

@@ -140,8 +140,9 @@ struct uvaia_gpu_ctx {
   int4 *d_rt = nullptr, *d_tr = nullptr;   // [pool_pad]
   uint8_t *d_entered = nullptr;  // [pool_pad] (push) or [db_cap] (resident)
   size_t entered_cap = 0;
-  uint8_t *d_stage = nullptr;    // device staging for raw characters (PACK_CHUNK rows)
-  uint8_t *h_stage = nullptr;    // pinned host staging
+  uint8_t *d_stage = nullptr;    // device staging for raw characters (2 x PACK_CHUNK rows)
+  uint8_t *h_stage = nullptr;    // pinned host staging (2 x PACK_CHUNK rows)
+  hipEvent_t stage_free[2] = {}; bool stage_busy[2] = {};
   size_t pitch = 0;
   // resident database
   uint4 *d_db = nullptr;
@@ -422,22 +423,26 @@ static int settle_derive(uvaia_gpu_ctx *c)
 int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t rows_pitch, const int *non_n, int n_ref,
               uint4 *tiles, int *nonn_dev, int *amb_dev, int *tot_dev, long long slot0)
 {
-  for (int done = 0; done < n_ref; done += PACK_CHUNK) {
+  // two staging buffers: while chunk k crosses PCIe and is packed, the host threads copy chunk k + 1 into the other pinned buffer
+  // (the hand-over of raw characters, 30 KB per reference, is what bounds the streaming entry points, not the kernels)
+  for (int done = 0, k = 0; done < n_ref; done += PACK_CHUNK, k ^= 1) {
     const int m = std::min(PACK_CHUNK, n_ref - done);
-    for (int i = 0; i < m; i++) {
+    if (c->stage_busy[k]) { HIPCHK(c, hipEventSynchronize(c->stage_free[k])); c->stage_busy[k] = false; }     // its previous chunk has left the buffer
+    uint8_t *hs = c->h_stage + (size_t)k * PACK_CHUNK * c->pitch, *ds = c->d_stage + (size_t)k * PACK_CHUNK * c->pitch;
+    for (int i = 0; i < m; i++) if (!(seq ? seq[done + i] : rows)) return fail(c, UVAIA_GPU_EINVAL, "NULL sequence at position %d", done + i);
+    parallel_for(m, [&](int i) {
       const char *src = seq ? seq[done + i] : rows + (size_t)(done + i) * rows_pitch;
-      if (!src) return fail(c, UVAIA_GPU_EINVAL, "NULL sequence at position %d", done + i);
-      memcpy(c->h_stage + (size_t)i * c->pitch, src, (size_t)c->nchar);
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_stage, c->h_stage, (size_t)m * c->pitch, hipMemcpyHostToDevice, c->stream));
+      memcpy(hs + (size_t)i * c->pitch, src, (size_t)c->nchar);
+    });
+    HIPCHK(c, hipMemcpyAsync(ds, hs, (size_t)m * c->pitch, hipMemcpyHostToDevice, c->stream));
     const long long s0 = slot0 + done, t0 = s0 / 64, t1 = (s0 + m - 1) / 64;
     const int nblk = (int)(t1 - t0 + 1);
     int *nn_out = non_n ? nullptr : nonn_dev;
-    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, (int *)nullptr, tot_dev, c->d_err);
-    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, c->d_stage, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, amb_dev, tot_dev, c->d_err);
+    if (c->acgt) hipLaunchKernelGGL((pack_refs_kernel<3>), dim3(nblk), dim3(256), 0, c->stream, ds, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, (int *)nullptr, tot_dev, c->d_err);
+    else         hipLaunchKernelGGL((pack_refs_kernel<4>), dim3(nblk), dim3(256), 0, c->stream, ds, c->pitch, c->nchar, s0, m, c->W4, tiles, t0, nn_out, amb_dev, tot_dev, c->d_err);
     HIPCHK(c, hipGetLastError());
     if (non_n) HIPCHK(c, hipMemcpyAsync(nonn_dev + s0, non_n + done, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // h_stage is reused by the next round
+    HIPCHK(c, hipEventRecord(c->stage_free[k], c->stream)); c->stage_busy[k] = true;
   }
   { int rc = derive_rows(c, tiles, slot0, n_ref); if (rc) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));     // scans may start on another stream: the packed and derived planes must be complete
@@ -470,6 +475,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
+  for (int i = 0; i < 2; i++) if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
   for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); if (c->d_rtb[i]) hipFree(c->d_rtb[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
   if (c->derive_stream) { hipStreamSynchronize(c->derive_stream); hipStreamDestroy(c->derive_stream); }
@@ -832,9 +838,10 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   OPENCHK(hipMemset(c->d_tr, 0, c->pool_pad * sizeof(int4)));
   OPENCHK(hipMalloc(&c->d_entered, c->pool_pad)); c->entered_cap = c->pool_pad;
   OPENCHK(hipMemset(c->d_entered, 0, c->pool_pad));
-  OPENCHK(hipMalloc(&c->d_stage, (size_t)PACK_CHUNK * c->pitch));
-  OPENCHK(hipHostMalloc(&c->h_stage, (size_t)PACK_CHUNK * c->pitch, hipHostMallocDefault));
-  memset(c->h_stage, 'N', (size_t)PACK_CHUNK * c->pitch);
+  OPENCHK(hipMalloc(&c->d_stage, (size_t)2 * PACK_CHUNK * c->pitch));
+  OPENCHK(hipHostMalloc(&c->h_stage, (size_t)2 * PACK_CHUNK * c->pitch, hipHostMallocDefault));
+  memset(c->h_stage, 'N', (size_t)2 * PACK_CHUNK * c->pitch);
+  for (int i = 0; i < 2; i++) OPENCHK(hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming));
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int) + 128;      // heap + the listed-words bitmap of replay2_kernel
   if (lds > 64 * 1024) {
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Copies the results of tools/measure_round.sh (gpurun_out/measure/) into profiles/ under round-1 names and writes
-profiles/r01_pmc_traffic.json, the block bench.py quotes for `roofline.traffic`.  Usage: python tools/collect_profiles.py"""
+"""Copies the results of tools/measure_round.sh (gpurun_out/measure/) into profiles/ under round-2 names and writes
+profiles/r02_pmc_traffic.json, the block bench.py quotes for `roofline.traffic` (only for the build of the kernels it was measured
+on: it carries the hash of the kernel sources).  Usage: python tools/collect_profiles.py"""
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 M = os.path.join(ROOT, "gpurun_out", "measure")
 P = os.path.join(ROOT, "profiles")
 
@@ -15,19 +18,23 @@ def last_json(path):
 
 
 def main():
-    for src, dst in (("bench_c2.json", "r01_bench_c2_final.json"), ("bench_acgt_c2.json", "r01_bench_c2_acgt.json"), ("bench_c3.json", "r01_bench_c3_acgt_10kx1M.json"),
-                     ("sweep_q1.json", "r01_sweep_q1_1Mrefs.json"), ("sweep_q4.json", "r01_sweep_q4_1Mrefs.json"), ("sweep_q16.json", "r01_sweep_q16_1Mrefs.json"),
-                     ("sweep_q64.json", "r01_sweep_q64_1Mrefs.json"), ("stats/c2_kernel_stats.csv", "r01_bench_c2_kernel_stats_final.csv"),
-                     ("pmc_fetch/f_counter_collection.csv", "r01_pmc_fetch_counter_collection.csv"), ("pmc_write/w_counter_collection.csv", "r01_pmc_write_counter_collection.csv"),
-                     ("pmc_fetch_q4/f_counter_collection.csv", "r01_pmc_fetch_q4_counter_collection.csv"),
-                     ("pmc_sqa/a_counter_collection.csv", "r01_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r01_pmc_sq_b_counter_collection.csv"),
-                     ("hbm_read.txt", "r01_hbm_read_ceiling.txt"), ("emu_2.json", "r01_emulated_query_shard_of_2.json"), ("emu_4.json", "r01_emulated_query_shard_of_4.json"),
-                     ("emu_8.json", "r01_emulated_query_shard_of_8.json")):
+    import bench
+    for src, dst in (("bench_default.json", "r02_bench_default.json"), ("bench_acgt_c1.json", "r02_bench_c1_acgt.json"),
+                     ("stats/c1_kernel_stats.csv", "r02_bench_c1_kernel_stats.csv"),
+                     ("pmc_fetch/f_counter_collection.csv", "r02_pmc_fetch_counter_collection.csv"), ("pmc_write/w_counter_collection.csv", "r02_pmc_write_counter_collection.csv"),
+                     ("pmc_fetch_q4/f_counter_collection.csv", "r02_pmc_fetch_q4_counter_collection.csv"),
+                     ("pmc_sqa/a_counter_collection.csv", "r02_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r02_pmc_sq_b_counter_collection.csv"),
+                     ("q4/q4_kernel_stats.csv", "r02_q4_1Mrefs_kernel_stats.csv"), ("q4/q4_kernel_trace.csv", "r02_q4_1Mrefs_kernel_trace.csv"),
+                     ("hbm_read.txt", "r02_hbm_read_ceiling.txt"), ("push_rate.json", "r02_push_rate.json"), ("ingest.json", "r02_ingest_text_vs_packed.json"),
+                     ("emu_refshard_2.json", "r02_emulated_reference_shards_2.json"), ("emu_refshard_4.json", "r02_emulated_reference_shards_4.json"),
+                     ("emu_refshard_8.json", "r02_emulated_reference_shards_8.json")):
         if os.path.exists(os.path.join(M, src)):
             shutil.copyfile(os.path.join(M, src), os.path.join(P, dst))
+    if not os.path.exists(os.path.join(M, "pmc_summary.json")):
+        print("no PMC passes to summarise")
+        return
     summ = json.load(open(os.path.join(M, "pmc_summary.json")))
-    bench = last_json(os.path.join(M, "bench_c2.json"))
-    q4 = last_json(os.path.join(M, "sweep_q4.json"))
+    b = last_json(os.path.join(M, "bench_default.json"))
 
     def pick(block, name):
         for k, v in summ.get(block, {}).items():
@@ -35,35 +42,37 @@ def main():
                 return v
         return {}
 
+    out = {"note": "rocprofv3 --pmc, one counter group per pass (tools/measure_round.sh). FETCH_SIZE/WRITE_SIZE are KB per dispatch; gfx950 FETCH_SIZE "
+                   "reports half of wide coalesced reads (MI355X_MICROARCH.md), hence x2; checked on the packed-plane scan of the Q = 4 run below, which has to read "
+                   "every packed byte exactly once. FETCH_SIZE counts L2 misses (Infinity-Cache hits included).",
+           "kernel_source_hash": bench.kernel_source_hash(), "raw": summ}
     scan_f, scan_w = pick("config1_fetch", "scan3_kernel"), pick("config1_write", "scan3_kernel")
-    # full-size launches only (a step may end with a shorter slice): use the maximum per dispatch
-    fetch_kb, write_kb = scan_f["FETCH_SIZE"]["max"], scan_w["WRITE_SIZE"]["max"]
-    q4_kb = pick("q4_1Mrefs_fetch", "scan3_kernel")["FETCH_SIZE"]["mean"]
-    # the PMC pass on 4 queries measures the column-compressed scan (forced: 4 queries get the packed-plane scan by default), whose
-    # bytes per reference at 4 queries are 4 148 (uvaia_gpu_scan_bytes_per_ref); the sweep file may describe the other kernel
-    q4_bpr = q4["roofline"]["kernel_bytes_per_ref"] if q4["roofline"]["kernel"] == "scan3_kernel" else 4148
-    q4_alg = q4_bpr * q4["config"]["refs_per_gpu"]
-    out = {
-        "note": "rocprofv3 --pmc, one counter group per pass (tools/measure_round.sh). FETCH_SIZE/WRITE_SIZE are KB per dispatch; gfx950 FETCH_SIZE "
-                "reports half of wide coalesced reads (MI355X_MICROARCH.md), hence x2. Check on the one-launch Q=4 run below: corrected fetch / bytes the kernel "
-                "has to read. FETCH_SIZE counts L2 misses (Infinity-Cache hits included).",
-        "scan3_kernel": {
-            "config": {"queries": bench["config"]["queries"], "refs_per_gpu": bench["config"]["refs_per_gpu"], "pool": bench["config"]["pool"], "mode": bench["config"]["mode"]},
-            "variant": "",
-            "hbm_side_read_bytes_per_launch": fetch_kb * 1024 * 2, "write_bytes_per_launch": write_kb * 1024,
-            "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-            "kernel_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] * bench["roofline"]["kernel_bytes_per_ref"] / bench["roofline"]["algorithmic_bytes_per_ref"],
-        },
-        "q4_1Mrefs_one_launch_check": {"kernel": "scan3_kernel (UVAIA_GPU_SCAN=compressed)", "fetch_bytes_corrected": q4_kb * 1024 * 2, "kernel_bytes": q4_alg, "ratio": q4_kb * 1024 * 2 / q4_alg},
-        "raw": summ,
-    }
-    sqa, sqb = pick("config1_sq_a", "scan3_kernel"), pick("config1_sq_b", "scan3_kernel")
-    if sqa and sqb:
-        tot = {k: v["sum"] for k, v in {**sqa, **sqb}.items()}
-        n_instr = sum(tot.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
-        out["scan3_kernel"]["instruction_mix_all_dispatches"] = tot
-        out["scan3_kernel"]["wave_instructions_all_dispatches"] = n_instr
-    json.dump(out, open(os.path.join(P, "r01_pmc_traffic.json"), "w"), indent=1)
+    if scan_f and scan_w:
+        # full-size launches only (a step may end with a shorter slice): the maximum per dispatch
+        fetch_kb, write_kb = scan_f["FETCH_SIZE"]["max"], scan_w["WRITE_SIZE"]["max"]
+        e = {"config": {"queries": b["config"]["queries"], "refs_per_gpu": b["config"]["refs_per_gpu"], "pool": b["config"]["pool"], "mode": b["config"]["mode"]},
+             "hbm_side_read_bytes_per_launch": fetch_kb * 1024 * 2, "write_bytes_per_launch": write_kb * 1024,
+             "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
+             "kernel_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"] * b["roofline"]["kernel_bytes_per_ref"] / b["roofline"]["algorithmic_bytes_per_ref"]}
+        sqa, sqb = pick("config1_sq_a", "scan3_kernel"), pick("config1_sq_b", "scan3_kernel")
+        if sqa and sqb:
+            tot = {k: v["sum"] for k, v in {**sqa, **sqb}.items()}
+            n_instr = sum(tot.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+            n_disp = sqa["SQ_INSTS_VALU"]["n"]
+            per_launch = n_instr / n_disp
+            rate = per_launch / (b["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+            e["instruction_mix_all_dispatches"] = tot
+            e["wave_instructions_per_launch"] = per_launch
+            e["issue"] = {"wave_instructions_per_launch": round(per_launch), "achieved": round(rate, 1), "peak": 1037.0, "unit": "G wave-instr/s", "frac": round(rate / 1037.0, 3),
+                          "mix": {k[9:]: round(tot[k] / n_instr, 3) for k in tot if k.startswith("SQ_INSTS_")},
+                          "source": "SQ passes of this file over avg_launch_ms of the bench line; peak: profiles/r01_issue_rate_microbench.txt (VALU + SALU mixed, whole chip)"}
+        out["scan3_kernel"] = e
+    q4f = pick("q4_1Mrefs_fetch", "scan2_iupac_kernel")
+    if q4f:
+        total_kb = q4f["FETCH_SIZE"]["sum"] / (q4f["FETCH_SIZE"]["n"] / 5.0)        # five launches per step (short head and tail slices)
+        out["q4_1Mrefs_check"] = {"kernel": "scan2_iupac_kernel", "fetch_bytes_corrected_per_step": total_kb * 1024 * 2, "packed_bytes_per_step": 1000000 * 14976,
+                                  "ratio": total_kb * 1024 * 2 / (1000000 * 14976.0)}
+    json.dump(out, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
     print("profiles updated")
 
 

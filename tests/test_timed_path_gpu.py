@@ -171,3 +171,24 @@ def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt):
             assert tuple(int(x) for x in want[j, iq]) == s, "reference %d, query %d" % (o, iq)
             checked += 1
     assert checked >= len(sample)
+
+
+@pytest.mark.parametrize("nq", [100, 40, 70])
+def test_slice_longer_than_the_pool_with_a_partial_super_tile(nq):
+    """`uvaia --packed -p 8192` on 100 queries x 100 000 references: without constant-and-complete query columns pools have no effect,
+    the slices are laid over the whole stream and the counter buffers grow past nq_pad x max_pool.  Their row count has to cover the
+    whole last super-tile of 64 queries the scan writes (100 queries: rows 0..127), not the last tile of 16."""
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(QUERY_INDEX0, nq)
+    qn = _names(nq, "query_")
+    refs, _ = gen.generate_bytes(0, 2500)
+    oq = O.Query(qs, qn)
+    assert len(oq.idx_c) == 0
+    gold = O.search(oq, refs, _names(len(refs)), pool=128, nbest=20, ambig_r=0.5)
+    pq = hostlib.PreparedQuery(qs, qn)
+    with pq.open_engine(nbest=20, max_pool=128) as eng:
+        _load(eng, gen, 0, len(refs))
+        for _ in range(2):
+            rows, T, ent = _timed_step(eng, 128)
+            assert rows == _want(gold, oq.ntax) and T == gold.final_T
+            assert list(np.nonzero(ent)[0]) == list(gold.saved)

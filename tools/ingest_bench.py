@@ -38,7 +38,10 @@ def main():
 
     def run(cmd, tag=None):
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if r.returncode:
+            sys.stderr.write("FAILED (%d): %s\n%s\n" % (r.returncode, " ".join(cmd), r.stderr.decode(errors="replace")[-3000:]))
+            sys.exit(1)
         if tag:
             logs[tag] = [l for l in r.stderr.decode(errors="replace").splitlines() if "secs" in l]
         return time.perf_counter() - t0

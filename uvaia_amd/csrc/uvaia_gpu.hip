@@ -1359,7 +1359,9 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   if (n > c->max_pool && c->n_idx_c > 0) return fail(c, UVAIA_GPU_EINVAL, "slice of %zu references above max_pool %zu", n, c->max_pool);
   {
     const size_t ppad_ = ((first + n + 63) / 64 - first / 64) * 64;
-    const size_t rows = std::min<size_t>((size_t)c->nq_pad, ((size_t)c->act_q1 + 15) / 16 * 16);     // the scan writes whole query tiles up to the last active one
+    // the scans write whole query tiles up to the last active one: super-tiles of 64 queries (scan3_kernel), tiles of 16 otherwise
+    const size_t qtile = c->scan_variant == 2 ? 64 : 16;
+    const size_t rows = std::min<size_t>((size_t)c->nq_pad, ((size_t)c->act_q1 + qtile - 1) / qtile * qtile);
     const size_t need = std::max(rows * ppad_, buf == 0 ? c->slice_cap[0] : (size_t)0);
     if (need > c->slice_cap[buf] || !c->d_tmin[buf]) {
       for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
@@ -1372,7 +1374,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
       HIPCHK(c, hipMalloc(&c->d_tmin[buf], (cap / 64) * sizeof(int2)));
       if (c->d_rtb[buf]) hipFree(c->d_rtb[buf]);
       c->d_rtb[buf] = nullptr;
-      HIPCHK(c, hipMalloc(&c->d_rtb[buf], (cap / (size_t)c->nq_pad + 64) * sizeof(int4)));
+      HIPCHK(c, hipMalloc(&c->d_rtb[buf], (std::max(cap / (size_t)c->nq_pad, ppad_) + 64) * sizeof(int4)));
       if (c->d_mp[0] || (c->acgt && c->scan_variant == 2)) { if (c->d_mp[buf]) hipFree(c->d_mp[buf]); c->d_mp[buf] = nullptr; HIPCHK(c, hipMalloc(&c->d_mp[buf], cap * sizeof(int))); }
       c->slice_cap[buf] = cap;
     }

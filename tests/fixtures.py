@@ -68,3 +68,43 @@ def synth_alignment(n, L, seed, p_snp=0.002, p_amb=0.0005, n_run_frac=0.1, root=
             s[a:a + rng.integers(1, max(2, L // 60))] = ord("N")
         out.append(s.tobytes())
     return out, root, poly_cols
+
+
+def unaligned_queries(ref, n, seed, p_snp=0.001, p_indel=0.0002, max_indel=12, n_runs=(90, 75, 350), run_prob=0.5, ambiguity=0.0003):
+    """Unaligned sequences shaped like the input of uvaialign: the reference with SNPs, short insertions and deletions, sparse
+    IUPAC codes, and N runs (leading, trailing, one amplicon-sized dropout), as bytes of differing lengths."""
+    rng = np.random.default_rng(seed)
+    acgt = b"ACGT"
+    amb = b"YRKMSW"
+    out = []
+    for _ in range(n):
+        s = bytearray()
+        i, L = 0, len(ref)
+        while i < L:
+            r = rng.random()
+            if r < p_snp:
+                s.append(acgt[rng.integers(0, 4)]); i += 1
+            elif r < p_snp + p_indel:
+                i += int(rng.integers(1, max_indel + 1))                                  # deletion
+            elif r < p_snp + 2 * p_indel:
+                s.extend(acgt[j] for j in rng.integers(0, 4, size=int(rng.integers(1, max_indel + 1))))   # insertion
+            elif r < p_snp + 2 * p_indel + ambiguity:
+                s.append(amb[rng.integers(0, len(amb))]); i += 1
+            else:
+                s.append(ref[i]); i += 1
+        if not s:
+            s.append(acgt[0])
+        lead, trail, drop = n_runs
+        if lead and rng.random() < run_prob:
+            k = min(len(s), int(rng.integers(1, lead + 1))); s[:k] = b"N" * k
+        if trail and rng.random() < run_prob:
+            k = min(len(s), int(rng.integers(1, trail + 1))); s[len(s) - k:] = b"N" * k
+        if drop and rng.random() < run_prob and len(s) > 2:
+            k = int(rng.integers(1, drop + 1)); a = int(rng.integers(0, max(1, len(s) - k))); k = min(k, len(s) - a); s[a:a + k] = b"N" * k
+        out.append(bytes(s))
+    return out
+
+
+def random_acgt(n, seed):
+    rng = np.random.default_rng(seed)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n, p=[0.299, 0.184, 0.196, 0.321])].tobytes()

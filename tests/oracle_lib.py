@@ -30,12 +30,18 @@ class OrcQuery(C.Structure):
     ]
 
 
+class WfaPenalties(C.Structure):
+    _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gap_opening", C.c_int), ("gap_extension", C.c_int)]
+
+
+UVAIALIGN_PENALTIES = (0, 4, 6, 2)          # src/align.c:305
+
 _lib = None
 
 
 def build():
     """(Re)build liboracle.so if missing or stale."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("uvaia_oracle.c", "uvaia_oracle.h", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("uvaia_oracle.c", "uvaia_oracle.h", "wfa_oracle.c", "wfa_oracle.h", "Makefile")]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
@@ -82,6 +88,27 @@ def lib():
     L.orc_count_non_N.argtypes = [C.c_char_p, C.c_size_t]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_max_threads.restype = C.c_int
+    # uvaialign (wfa_oracle.h)
+    L.orc_wfa_new.restype = C.c_void_p
+    L.orc_wfa_new.argtypes = [WfaPenalties, C.c_int, C.c_int]
+    L.orc_wfa_del.argtypes = [C.c_void_p]
+    L.orc_wfa_align.restype = C.c_int
+    L.orc_wfa_align.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    L.orc_wfa_cigar.restype = C.POINTER(C.c_char)
+    L.orc_wfa_cigar.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.orc_wfa_cells.restype = C.c_int64
+    L.orc_wfa_cells.argtypes = [C.c_void_p]
+    L.orc_wfa_max_width.restype = C.c_int
+    L.orc_wfa_max_width.argtypes = [C.c_void_p]
+    L.orc_uvaialign_query.restype = C.c_int
+    L.orc_uvaialign_query.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]
+    L.orc_uvaialign_accepts.restype = C.c_int
+    L.orc_uvaialign_accepts.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_double]
+    L.orc_uvaialign_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, pp, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_int)]
+    L.orc_gotoh_score.restype = C.c_int
+    L.orc_gotoh_score.argtypes = [WfaPenalties, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.orc_cigar_score.restype = C.c_int
+    L.orc_cigar_score.argtypes = [WfaPenalties, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     _lib = L
     return L
 
@@ -204,3 +231,52 @@ def search(query, refs, names, pool=64, nbest=100, ambig_r=0.5, exclude_self=Fal
         return res
     finally:
         L.orc_search_del(s)
+
+
+# ---- uvaialign (oracle/wfa_oracle.h) ----
+def wfa_align(pattern, text, penalties=UVAIALIGN_PENALTIES, min_wavefront_length=128, max_distance_threshold=512, max_score=1 << 30):
+    """(score, cigar bytes, M-wavefront cells, widest wavefront); min_wavefront_length <= 0: complete wavefronts."""
+    L = lib()
+    w = L.orc_wfa_new(WfaPenalties(*penalties), min_wavefront_length, max_distance_threshold)
+    try:
+        score = L.orc_wfa_align(w, pattern, len(pattern), text, len(text), max_score)
+        n = C.c_int(0)
+        ops = L.orc_wfa_cigar(w, C.byref(n))
+        cigar = C.string_at(ops, n.value) if score >= 0 else b""
+        return score, cigar, L.orc_wfa_cells(w), L.orc_wfa_max_width(w)
+    finally:
+        L.orc_wfa_del(w)
+
+
+def gotoh_score(pattern, text, penalties=UVAIALIGN_PENALTIES):
+    return lib().orc_gotoh_score(WfaPenalties(*penalties), pattern, len(pattern), text, len(text))
+
+
+def cigar_score(cigar, pattern, text, penalties=UVAIALIGN_PENALTIES):
+    return lib().orc_cigar_score(WfaPenalties(*penalties), cigar, len(cigar), pattern, len(pattern), text, len(text))
+
+
+def uvaialign_query(ref, seq):
+    """(score, aligned row of len(ref) bytes, cells) as src/align.c:357-390 produces it."""
+    out = C.create_string_buffer(len(ref) + 1)
+    cells = C.c_int64(0)
+    score = lib().orc_uvaialign_query(ref, len(ref), seq, len(seq), out, C.byref(cells))
+    return score, out.raw[:len(ref)], cells.value
+
+
+def uvaialign_accepts(seq, ref_len, ambiguity=0.5):
+    return bool(lib().orc_uvaialign_accepts(seq, len(seq), ref_len, ambiguity))
+
+
+def uvaialign_batch(ref, seqs, threads=None):
+    """scores [n] and aligned rows [n, len(ref)] over OpenMP threads (src/align.c:224-233)."""
+    L = lib()
+    if threads:
+        L.orc_set_threads(threads)
+    n = len(seqs)
+    rows = np.zeros((n, len(ref) + 1), dtype=np.uint8)
+    score = np.zeros(n, dtype=np.int32)
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    L.orc_uvaialign_batch(ref, len(ref), n, _cstr_array(seqs), lens.ctypes.data_as(C.POINTER(C.c_int)),
+                          rows.ctypes.data_as(C.c_char_p), score.ctypes.data_as(C.POINTER(C.c_int)))
+    return score, rows[:, :len(ref)]

@@ -25,9 +25,28 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_align_header_symbols_all_exported(lib):
+    from uvaia_amd import align
+    hdr = open(os.path.join(ROOT, "include", "uvaia_align.h")).read()
+    declared = set(re.findall(r"\b(uvaia_align_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(align.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_aligner_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from uvaia_amd import align
+    with pytest.raises(align.AlignError) as ei:
+        align.Aligner(b"ACGTACGTAC")
+    assert ei.value.code == -2          # UVAIA_ALIGN_ENODEV
+
+
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "uvaia_gpu.h"\nint main(void){ uvaia_gpu_ctx *c = 0; (void)c; return UVAIA_GPU_OK; }\n')
+    src.write_text('#include "uvaia_gpu.h"\n#include "uvaia_align.h"\nint main(void){ uvaia_gpu_ctx *c = 0; uvaia_aligner *a = 0; (void)c; (void)a; return UVAIA_GPU_OK + UVAIA_ALIGN_OK; }\n')
     import subprocess
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 

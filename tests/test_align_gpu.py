@@ -1,0 +1,114 @@
+"""The wavefront aligner of `uvaialign` on the MI355X against the CPU restatement (`pytest -m gpu`): scores and aligned rows bit
+for bit (oracle/wfa_oracle.c; the WFA library itself is an absent submodule, so what is compared is the published algorithm as
+the oracle states it: see tests/test_wfa_oracle.py for what pins the oracle)."""
+import numpy as np
+import pytest
+
+import fixtures as F
+import oracle_lib as O
+from uvaia_amd import align
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ref, seqs, al, **oracle_kw):
+    score, rows = al.align(seqs)
+    for i, t in enumerate(seqs):
+        if oracle_kw:
+            want, cigar, _, _ = O.wfa_align(ref, t, **oracle_kw)
+            row = bytearray()
+            pos = 0
+            for op in cigar:
+                if op in b"MX":
+                    row.append(t[pos]); pos += 1
+                elif op == ord("I"):
+                    pos += 1
+                else:
+                    row.append(ord("-"))
+            want_row = bytes(row)
+        else:
+            want, want_row, _ = O.uvaialign_query(ref, t)
+        assert score[i] == want, (i, score[i], want)
+        assert rows[i].tobytes() == want_row, i
+    return score
+
+
+def test_small_random_pairs_equal_oracle():
+    """lengths 1..400, heavy divergence, indels, N runs: every branch of the recurrences and of the backtrace"""
+    rng = np.random.default_rng(5)
+    for rep in range(12):
+        L = int(rng.integers(1, 400))
+        ref = F.random_acgt(L, 100 + rep)
+        seqs = F.unaligned_queries(ref, 40, 200 + rep, p_snp=0.05, p_indel=0.02, max_indel=8, n_runs=(10, 10, 40), run_prob=0.4, ambiguity=0.01)
+        seqs += [ref, ref[: max(1, L // 3)], ref + ref[: L // 2], b"A", b"N" * max(1, L // 2)]
+        with align.Aligner(ref) as al:
+            _check(ref, seqs, al)
+
+
+def test_sars_cov_2_shaped_queries_equal_oracle():
+    """29 903-column reference, queries with SNPs, short indels, leading/trailing N runs and an amplicon dropout: long wavefronts,
+    the adaptive reduction at work (widths above 128), match runs of thousands of characters"""
+    ref = F.random_acgt(29903, 7)
+    seqs = F.unaligned_queries(ref, 96, 8)
+    with align.Aligner(ref) as al:
+        score = _check(ref, seqs, al)
+        st = al.stats()
+    assert st["passes"] == 1 and st["cells"] > 0
+    assert score.max() > 600                                   # N runs cost 4 per site: the reduction is in play
+
+
+def test_resident_pool_and_repeat_runs_agree():
+    ref = F.random_acgt(5000, 9)
+    seqs = F.unaligned_queries(ref, 300, 10, n_runs=(50, 40, 200))
+    gold_score, gold_rows = O.uvaialign_batch(ref, seqs)
+    with align.Aligner(ref) as al:
+        al.load(seqs)
+        for _ in range(2):
+            al.run()
+            score, rows = al.fetch()
+            assert np.array_equal(score, gold_score) and np.array_equal(rows, gold_rows)
+
+
+@pytest.mark.parametrize("opts", [dict(min_wavefront_length=0), dict(mismatch=3, gap_opening=5, gap_extension=1), dict(mismatch=2, gap_opening=12, gap_extension=3),
+                                  dict(min_wavefront_length=16, max_distance_threshold=20), dict(mismatch=1, gap_opening=0, gap_extension=1)])
+def test_options_follow_the_oracle(opts):
+    ref = F.random_acgt(1500, 13)
+    seqs = F.unaligned_queries(ref, 24, 14, p_snp=0.01, p_indel=0.003, n_runs=(30, 30, 120))
+    d = align.default_options()
+    pen = (0, opts.get("mismatch", d.mismatch), opts.get("gap_opening", d.gap_opening), opts.get("gap_extension", d.gap_extension))
+    kw = dict(penalties=pen, min_wavefront_length=opts.get("min_wavefront_length", d.min_wavefront_length),
+              max_distance_threshold=opts.get("max_distance_threshold", d.max_distance_threshold))
+    with align.Aligner(ref, **opts) as al:
+        _check(ref, seqs, al, **kw)
+
+
+def test_queries_that_overflow_their_share_are_run_again():
+    """a small workspace: the N-rich queries do not fit the first pass's share and finish in a later pass with a larger one"""
+    ref = F.random_acgt(6000, 17)
+    seqs = F.unaligned_queries(ref, 64, 18, n_runs=(90, 75, 350), run_prob=0.7)
+    with align.Aligner(ref, workspace_bytes=64 << 20, max_blocks=64) as al:
+        _check(ref, seqs, al)
+        assert al.stats()["passes"] >= 2
+
+
+def test_a_query_beyond_the_whole_workspace_is_an_error_not_a_wrong_row():
+    ref = F.random_acgt(20000, 19)
+    with align.Aligner(ref, workspace_bytes=64 << 20, max_blocks=4) as al:
+        with pytest.raises(align.AlignError) as ei:
+            al.align([b"N" * 15000])
+        assert ei.value.code == -3
+
+
+def test_bad_arguments():
+    with pytest.raises(align.AlignError):
+        align.Aligner(b"ACGT", mismatch=0)
+    with pytest.raises(align.AlignError):
+        align.Aligner(b"ACGT", mismatch=64)
+    with align.Aligner(b"ACGTACGT") as al:
+        with pytest.raises(align.AlignError) as ei:
+            al.fetch()                                   # nothing has run yet
+        assert ei.value.code == -5
+        score, rows = al.align([])
+        assert len(score) == 0 and rows.shape == (0, 8)
+        score, rows = al.align([b"ACGTTACGT"])
+        assert score[0] == 8 and rows[0].tobytes() == b"ACGTACGT"

@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
     ap.add_argument("--no-sweep", action="store_true", help="headline workload only (profiling runs)")
     ap.add_argument("--sweep-refs", type=int, default=1000000, help="references of the sweep entries")
+    ap.add_argument("--align-queries", type=int, default=10000, help="queries of the uvaialign record (BASELINE config[4]; 0 = skip)")
+    ap.add_argument("--align-only", action="store_true", help="only the uvaialign record (profiling runs); prints {\"align\": ...}")
+    ap.add_argument("--align-cpu-queries", type=int, default=1024, help="queries of the uvaialign CPU-baseline sample (0 = skip)")
     return ap.parse_args(argv)
 
 
@@ -234,6 +237,79 @@ def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset
     return out
 
 
+def unaligned_from_rows(rows, rng):
+    """Aligned generator rows -> unaligned sequences as uvaialign receives them: gap characters dropped, then a few short
+    deletions and insertions (Poisson 2 each, 1..12 sites) so that the alignment has real gaps to find."""
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for r in rows:
+        s = r[r != ord("-")]
+        for _ in range(rng.poisson(2.0)):
+            a, k = int(rng.integers(0, len(s) - 16)), int(rng.integers(1, 13))
+            s = np.delete(s, slice(a, a + k))
+        for _ in range(rng.poisson(2.0)):
+            a, k = int(rng.integers(0, len(s))), int(rng.integers(1, 13))
+            s = np.insert(s, a, acgt[rng.integers(0, 4, size=k)])
+        out.append(s.tobytes())
+    return out
+
+
+def align_workload(hostlib, n_query, steps, nchar, seed, preset, device, n_cpu, n_check=48):
+    """uvaialign (src/align.c:224-233,357-390; BASELINE config[4]): n_query unaligned sequences against one reference on one GPU, the
+    pool resident in HBM; a step = uvaia_align_run (all wavefront passes + backtrace + projected rows, results left on the device)."""
+    from uvaia_amd import align
+    gen = hostlib.Synth(nchar, seed=seed, preset=1)                       # the reference: a clean sequence, what is not ACGT filled in
+    ref_row, _ = gen.generate(7, 1)
+    ref = np.array(ref_row[0], dtype=np.uint8)
+    bad = ~np.isin(ref, np.frombuffer(b"ACGT", dtype=np.uint8))
+    ref[bad] = ord("A")
+    ref = ref.tobytes()
+    gen = hostlib.Synth(nchar, seed=seed, preset=preset)
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for a in range(0, n_query, 2048):
+        rows, _ = gen.generate(QUERY_INDEX0 + a, min(2048, n_query - a))
+        seqs += unaligned_from_rows(np.asarray(rows, dtype=np.uint8), rng)
+    al = align.Aligner(ref, device=device)
+    al.load(seqs)
+    al.run()                                                              # warm-up (workspace allocation) and the answer
+    score, rows = al.fetch()
+    t_a = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(steps):
+        al.run()
+        kernel_ms += al.stats()["kernel_ms"]
+    elapsed = time.perf_counter() - t_a
+    st = al.stats()
+    al.close()
+    out = {"workload": ("BASELINE config[4]: " if (n_query, nchar) == (10000, 29903) else "") +
+           "uvaialign: %d unaligned queries (%d..%d characters) vs one reference of %d sites, penalties 0/4/6/2, reduced wavefronts 128/512" % (n_query, min(map(len, seqs)), max(map(len, seqs)), nchar),
+           "value": round(n_query * steps / elapsed, 1), "unit": "queries/s", "ms_per_pool": round(1e3 * elapsed / steps, 3), "steps": steps,
+           "kernel_ms_per_pool": round(kernel_ms / steps, 3), "kernel": "wfa_align_kernel", "passes": st["passes"],
+           "cells_per_query": round(st["cells"] / n_query), "median_score": int(np.median(score)), "max_score": int(score.max()),
+           "cell_updates_per_s": round(st["cells"] * steps / elapsed), "wavefront_bytes_per_cell": 32,
+           "wavefront_GBps": round(st["wavefront_bytes"] * steps / elapsed / 1e9, 1), "frac_of_hbm_peak": round(st["wavefront_bytes"] * steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+           "note": "a query is a chain of one dependent step per score (thousands), each a few to ~1 400 diagonals wide: the kernel is bound by the latency of that chain "
+                   "with one wavefront per query in flight, not by HBM; rows and scores equal the CPU restatement's (oracle/wfa_oracle.c; parity unpinned beyond the optimal score)"}
+    if os.path.join(ROOT, "tests") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    pick = list(range(0, n_query, max(1, n_query // n_check)))[:n_check]
+    g_score, g_rows = O.uvaialign_batch(ref, [seqs[i] for i in pick])
+    out["parity_on_sample"] = bool(np.array_equal(g_score, score[pick]) and np.array_equal(g_rows, rows[pick]))
+    if n_cpu > 0:
+        sample = seqs[:n_cpu]
+        threads = O.lib().orc_max_threads()
+        t0 = time.perf_counter(); O.uvaialign_batch(ref, sample); t_all = time.perf_counter() - t0
+        one = sample[:max(8, n_cpu // 64)]
+        t0 = time.perf_counter(); O.uvaialign_batch(ref, one, threads=1); t_one = time.perf_counter() - t0
+        O.lib().orc_set_threads(threads)
+        out["cpu_baseline"] = {"value": round(len(sample) / t_all, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+                               "sample": "the first %d queries of the same pool, OpenMP over %d threads, %.1f s" % (len(sample), threads, t_all),
+                               "value_1_thread": round(len(one) / t_one, 1), "sample_1_thread": "the first %d queries, 1 thread, %.1f s" % (len(one), t_one)}
+    return out
+
+
 def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_timed, n_one):
     """The oracle's restatement of the reference loops (src/nearest.c:249-330) on the host cores, with the heaps in the state a long
     run spends its time in: `n_warm` references are fed untimed (heaps fill, tolerances settle: the early exits of
@@ -363,6 +439,10 @@ def main():
     backend = os.environ.get("UVAIA_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    if args.align_only:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        print(json.dumps({"align": align_workload(hostlib, args.align_queries, args.steps, args.nchar, args.seed, args.preset, local_rank, args.align_cpu_queries)}))
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -510,7 +590,7 @@ def main():
     eng.close()
 
     # ---- other resident-query counts, driver-timed in the same run (rank 0, N=1 only)
-    sweep = ball = None
+    sweep = ball = aligned = None
     if rank == 0 and world == 1 and not emu and not args.no_sweep:
         sweep = []
         for nq_s, mode_s, steps_s in ((1, "iupac", 5), (4, "iupac", 5), (16, "iupac", 5), (10000, "acgt", 2)):
@@ -520,6 +600,8 @@ def main():
                 e["workload"] = "BASELINE config[2]: " + e["workload"]
             sweep.append(e)
         ball = ball_workload(hostlib, 1000, args.sweep_refs, 2, "iupac", 3, args.nchar, args.seed, args.preset, local_rank)
+        if args.align_queries > 0:
+            aligned = align_workload(hostlib, args.align_queries, 3, args.nchar, args.seed, args.preset, local_rank, args.align_cpu_queries)
 
     if rank == 0:
         out = {
@@ -553,6 +635,7 @@ def main():
             "parity_check_on_timed_path": parity,
             "sweep": sweep,
             "ball": ball,
+            "align": aligned,
         }
         print(json.dumps(out))
         sys.stdout.flush()

@@ -112,3 +112,52 @@ def test_bad_arguments():
         assert len(score) == 0 and rows.shape == (0, 8)
         score, rows = al.align([b"ACGTTACGT"])
         assert score[0] == 8 and rows[0].tobytes() == b"ACGTACGT"
+
+
+# ---- the drop-in command line (src/align.c main) ----
+import lzma
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UVAIALIGN = os.path.join(ROOT, "bin", "uvaialign")
+
+
+def _write_fasta(path, names, seqs, opener=open, width=None):
+    with opener(path, "wb") as fh:
+        for n, s in zip(names, seqs):
+            fh.write(b">" + n.encode() + b"\n")
+            if width:
+                for a in range(0, len(s), width):
+                    fh.write(s[a:a + width] + b"\n")
+            else:
+                fh.write(s + b"\n")
+
+
+def test_uvaialign_cli_matches_oracle(tmp_path):
+    """reference + two query files (one xz, one multi-line with lower case), small pools so that several batches run; rejected
+    sequences (size, N fraction) leave the stream as in src/align.c:199-221; --stdout and the compressed file hold the same rows"""
+    ref = F.random_acgt(4000, 51)
+    good = F.unaligned_queries(ref, 70, 52, n_runs=(60, 50, 200))
+    bad = [ref[:2000], b"N" * 2500 + ref[:1500], ref + ref]                        # too short, too many N, too long
+    seqs = good[:30] + bad[:1] + good[30:55] + bad[1:] + good[55:]
+    names = ["s%d" % i for i in range(len(seqs))]
+    _write_fasta(tmp_path / "ref.fa", ["the_ref", "second_record_is_ignored"], [ref, b"ACGT"], width=60)
+    half = 40
+    _write_fasta(tmp_path / "q1.fa.xz", names[:half], seqs[:half], opener=lzma.open)
+    _write_fasta(tmp_path / "q2.fa", names[half:], [s.lower() for s in seqs[half:]], width=70)
+    want = []
+    for n, s in zip(names, seqs):
+        if O.uvaialign_accepts(s, len(ref), 0.5):
+            want.append((n, O.uvaialign_query(ref, s)[1]))
+    assert len(want) == len(good)
+    cmd = [UVAIALIGN, "-r", str(tmp_path / "ref.fa"), str(tmp_path / "q1.fa.xz"), str(tmp_path / "q2.fa"), "-p", "16"]
+    r = subprocess.run(cmd + ["--stdout"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    got_names, got_rows = F.read_fasta_bytes(r.stdout)
+    assert [(n, s) for n, s in zip(got_names, got_rows)] == want
+    err = r.stderr.decode()
+    assert "has size too different from reference" in err and "proportion of N etc." in err
+    assert "Output %d aligned sequences." % len(want) in err
+    subprocess.run(cmd + ["-o", str(tmp_path / "out")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    with lzma.open(tmp_path / "out.aln.xz", "rb") as fh:
+        assert fh.read() == r.stdout

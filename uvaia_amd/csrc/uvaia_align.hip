@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void wfa_align_kernel(const uint8_t *__restrict
         const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
         if (type == 0) {
           const int nm = offset - max_all;
-          if (nm < 0) { broken = true; break; }
+          if (nm < 0 || (nm > 0 && (max_all < 0 || max_all - k < 0 || v > plen + 1 || h > tlen + 1))) { broken = true; break; }   // (a consistent backtrace never gets here)
           bool bad = false;
           for (int j0 = 0; j0 < nm; j0 += 64) {
             const int j = j0 + lane;
@@ -246,17 +246,17 @@ __global__ __launch_bounds__(64) void wfa_align_kernel(const uint8_t *__restrict
           offset = max_all;
           v = offset - k; h = offset;
         }
-        if (max_all == del_ext)       { if (lane == 0 && v > 0) row[v - 1] = '-'; s = s_e;  k++; type = 2; }
-        else if (max_all == del_open) { if (lane == 0 && v > 0) row[v - 1] = '-'; s = s_oe; k++; type = 0; }
+        if (max_all == del_ext)       { if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s = s_e;  k++; type = 2; }
+        else if (max_all == del_open) { if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s = s_oe; k++; type = 0; }
         else if (max_all == ins_ext)  { s = s_e;  k--; offset--; type = 1; }
         else if (max_all == ins_open) { s = s_oe; k--; offset--; type = 0; }
-        else if (max_all == misms)    { if (lane == 0 && v > 0 && h > 0) row[v - 1] = text[h - 1]; s = s_x; offset--; }
+        else if (max_all == misms)    { if (lane == 0 && v > 0 && h > 0 && v <= plen + 1) row[v - 1] = text[h - 1]; s = s_x; offset--; }
         else { broken = true; break; }
         v = offset - k; h = offset;
       }
       if (broken) status = ST_BACKTRACE;
-      else if (s == 0) { for (int j = lane; j < v; j += 64) row[j] = text[j]; }      // the last stroke of matches (k = 0 at score 0)
-      else { for (int j = lane; j < v; j += 64) row[j] = '-'; }                      // leading deletions; leading insertions leave no trace
+      else if (s == 0) { for (int j = lane; j < min(v, plen); j += 64) row[j] = text[j]; }      // the last stroke of matches (k = 0 at score 0)
+      else { for (int j = lane; j < min(v, plen); j += 64) row[j] = '-'; }                      // leading deletions; leading insertions leave no trace
       if (lane == 0) row[plen] = 0;
     }
     if (lane == 0) { score_out[q] = status == ST_OK ? score : -1; status_out[q] = status; }

@@ -47,7 +47,7 @@ typedef struct {
   int min_wavefront_length;                      /* <= 0: complete wavefronts (no reduction) */
   int max_distance_threshold;
   size_t workspace_bytes;                        /* device memory for the wavefronts of the queries in flight; 0 = chosen from the free memory */
-  int max_blocks;                                /* queries in flight (one wavefront each); 0 = as many as the chip holds */
+  int max_blocks;                                /* queries in flight (one block of four wavefronts each); 0 = as many as the chip holds */
 } uvaia_align_options;
 
 /* the reference's values: {4, 6, 2, 128, 512, 0, 0} */
@@ -74,8 +74,8 @@ int  uvaia_align_run (uvaia_aligner *a);
 int  uvaia_align_sync (uvaia_aligner *a);
 int  uvaia_align_fetch (uvaia_aligner *a, char *aln, int *score);
 
-/* work of the last run: M-wavefront cells computed, wavefront bytes written + read by the recurrences (12 + 20 per cell),
- * kernel passes (queries that overflow their share of the workspace are run again with a larger one), kernel time in ms */
+/* work of the last run: M-wavefront cells computed, wavefront bytes written + read by the recurrences (13 + 20 per cell),
+ * kernel passes (queries that find the workspace's pool empty are run again in a less crowded pass), kernel time in ms */
 int  uvaia_align_stats (uvaia_aligner *a, unsigned long long *cells, double *wavefront_bytes, int *passes, double *kernel_ms);
 
 #ifdef __cplusplus

@@ -1,7 +1,7 @@
 /*
  * wfa_oracle.c -- see wfa_oracle.h.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED for the aligner (third-party WFA
- * v1, absent from /root/reference/submodules/WFA).  Plain scalar C, one wavefront per malloc: this file is the
- * checker, written to be read next to the paper, not to be fast.
+ * v1, absent from /root/reference/submodules/WFA).  Plain scalar C written to be read next to the paper; wavefront memory
+ * comes from slabs the aligner keeps across alignments, one aligner per thread, as in the reference (src/align.c:304-310).
  */
 #include "wfa_oracle.h"
 #include "uvaia_oracle.h"
@@ -23,7 +23,10 @@ typedef struct {
   int *mem;                         /* offsets of lo_base..hi_base; offset = h (text position); v = h - k */
 } wavefront;
 
+typedef struct slab { struct slab *next; size_t cap, used; } slab;
+
 struct orc_wfa {
+  slab *slabs, *cur;                /* wavefront memory: slabs kept across alignments (the reference's aligners own an mm_allocator: src/align.c:306-308) */
   orc_wfa_penalties pen;
   int min_wavefront_length, max_distance_threshold;   /* min_wavefront_length <= 0: no reduction */
   wavefront **m, **i, **d;          /* per score; NULL = no wavefront at that score */
@@ -32,6 +35,23 @@ struct orc_wfa {
   char *ops; int ops_cap, ops_begin, ops_end;          /* CIGAR filled from the back by the backtrace */
   int64_t cells; int max_width;
 };
+
+static void *
+slab_alloc (orc_wfa *w, size_t bytes)
+{
+  bytes = (bytes + 15) & ~(size_t) 15;
+  while (w->cur && w->cur->used + bytes > w->cur->cap) { w->cur = w->cur->next; if (w->cur) w->cur->used = 0; }
+  if (!w->cur) {
+    size_t cap = bytes > ((size_t) 8 << 20) ? bytes : ((size_t) 8 << 20);         /* BUFFER_SIZE_8M, src/align.c:307 */
+    slab *sl = (slab *) malloc (sizeof (slab) + cap);
+    sl->next = NULL; sl->cap = cap; sl->used = 0;
+    if (!w->slabs) w->slabs = sl; else { slab *t = w->slabs; while (t->next) t = t->next; t->next = sl; }
+    w->cur = sl;
+  }
+  void *p = (char *) (w->cur + 1) + w->cur->used;
+  w->cur->used += bytes;
+  return p;
+}
 
 static int wf_get (const wavefront *w, int k) { return (w->lo <= k && k <= w->hi) ? w->mem[k - w->lo_base] : OFFSET_NULL; }
 
@@ -45,12 +65,10 @@ orc_wfa_new (orc_wfa_penalties pen, int min_wavefront_length, int max_distance_t
 }
 
 static void
-wf_free (wavefront **v, int n) { if (v) for (int s = 0; s < n; s++) if (v[s]) { free (v[s]->mem); free (v[s]); v[s] = NULL; } }
-
-static void
 clear_wavefronts (orc_wfa *w)
-{ /* affine_wavefronts_clear (src/align.c:360) */
-  wf_free (w->m, w->n_used); wf_free (w->i, w->n_used); wf_free (w->d, w->n_used);
+{ /* affine_wavefronts_clear (src/align.c:360): the wavefronts go, their memory stays with the aligner */
+  for (int s = 0; s < w->n_used; s++) w->m[s] = w->i[s] = w->d[s] = NULL;
+  w->cur = w->slabs; if (w->cur) w->cur->used = 0;
   w->n_used = 0; w->cells = 0; w->max_width = 0;
 }
 
@@ -58,7 +76,7 @@ void
 orc_wfa_del (orc_wfa *w)
 {
   if (!w) return;
-  clear_wavefronts (w);
+  for (slab *sl = w->slabs; sl; ) { slab *nx = sl->next; free (sl); sl = nx; }
   free (w->m); free (w->i); free (w->d); free (w->ops); free (w);
 }
 
@@ -76,11 +94,11 @@ reserve_scores (orc_wfa *w, int score)
 }
 
 static wavefront *
-wf_new (int lo, int hi)
+wf_new (orc_wfa *w, int lo, int hi)
 {
-  wavefront *f = (wavefront *) malloc (sizeof (wavefront));
+  wavefront *f = (wavefront *) slab_alloc (w, sizeof (wavefront) + (size_t) (hi - lo + 1) * sizeof (int));
   f->lo = f->lo_base = lo; f->hi = f->hi_base = hi; f->null = 0;
-  f->mem = (int *) malloc ((size_t) (hi - lo + 1) * sizeof (int));
+  f->mem = (int *) (f + 1);
   return f;
 }
 
@@ -160,9 +178,9 @@ compute_wavefront (orc_wfa *w, int score)
   int lo = m_sub->lo, hi = m_sub->hi;
   lo = MINI (lo, m_gap->lo); lo = MINI (lo, i_ext->lo); lo = MINI (lo, d_ext->lo); lo--;
   hi = MAXI (hi, m_gap->hi); hi = MAXI (hi, i_ext->hi); hi = MAXI (hi, d_ext->hi); hi++;
-  wavefront *out_m = w->m[score] = wf_new (lo, hi);
-  wavefront *out_i = (!m_gap->null || !i_ext->null) ? (w->i[score] = wf_new (lo, hi)) : NULL;
-  wavefront *out_d = (!m_gap->null || !d_ext->null) ? (w->d[score] = wf_new (lo, hi)) : NULL;
+  wavefront *out_m = w->m[score] = wf_new (w, lo, hi);
+  wavefront *out_i = (!m_gap->null || !i_ext->null) ? (w->i[score] = wf_new (w, lo, hi)) : NULL;
+  wavefront *out_d = (!m_gap->null || !d_ext->null) ? (w->d[score] = wf_new (w, lo, hi)) : NULL;
   w->cells += hi - lo + 1;
   if (hi - lo + 1 > w->max_width) w->max_width = hi - lo + 1;
   for (int k = lo; k <= hi; k++) {
@@ -235,7 +253,7 @@ orc_wfa_align (orc_wfa *w, const char *pattern, int plen, const char *text, int 
 { /* paper algorithm 1 */
   clear_wavefronts (w);
   reserve_scores (w, 0);
-  w->m[0] = wf_new (0, 0); w->m[0]->mem[0] = 0;
+  w->m[0] = wf_new (w, 0, 0); w->m[0]->mem[0] = 0;
   w->cells = 1; w->max_width = 1;
   int score = 0;
   for (;;) {
@@ -274,12 +292,19 @@ uvaialign_max_score (int ref_len)
   return ref_len * 4 + 6 + 2 * ref_len * 2;
 }
 
-int
-orc_uvaialign_query (const char *ref, int ref_len, const char *seq, int seq_len, char *aln, int64_t *cells)
+static int
+align_query (orc_wfa *w, const char *ref, int ref_len, const char *seq, int seq_len, char *aln)
 { /* src/align.c:357-364 */
-  orc_wfa *w = orc_wfa_new (uvaialign_penalties, 128, 512);
   int score = orc_wfa_align (w, ref, ref_len, seq, seq_len, uvaialign_max_score (ref_len));
   if (score >= 0) { int n; const char *ops = orc_wfa_cigar (w, &n); orc_align_project (ops, n, seq, aln); }
+  return score;
+}
+
+int
+orc_uvaialign_query (const char *ref, int ref_len, const char *seq, int seq_len, char *aln, int64_t *cells)
+{
+  orc_wfa *w = orc_wfa_new (uvaialign_penalties, 128, 512);       /* src/align.c:305-308 */
+  int score = align_query (w, ref, ref_len, seq, seq_len, aln);
   if (cells) *cells = orc_wfa_cells (w);
   orc_wfa_del (w);
   return score;
@@ -298,9 +323,14 @@ orc_uvaialign_accepts (const char *seq, size_t seq_len, size_t ref_len, double a
 
 void
 orc_uvaialign_batch (const char *ref, int ref_len, int n, const char *const *seqs, const int *seq_len, char *aln, int *score)
-{ /* src/align.c:224-233 */
-#pragma omp parallel for schedule(dynamic)
-  for (int c = 0; c < n; c++) score[c] = orc_uvaialign_query (ref, ref_len, seqs[c], seq_len[c], aln + (size_t) c * ((size_t) ref_len + 1), NULL);
+{ /* src/align.c:224-233 with one aligner per thread (new_queue, src/align.c:304-310) */
+#pragma omp parallel
+  {
+    orc_wfa *w = orc_wfa_new (uvaialign_penalties, 128, 512);
+#pragma omp for schedule(dynamic)
+    for (int c = 0; c < n; c++) score[c] = align_query (w, ref, ref_len, seqs[c], seq_len[c], aln + (size_t) c * ((size_t) ref_len + 1));
+    orc_wfa_del (w);
+  }
 }
 
 /* ---- independent checks ---- */

@@ -82,11 +82,12 @@ def test_options_follow_the_oracle(opts):
         _check(ref, seqs, al, **kw)
 
 
-def test_queries_that_overflow_their_share_are_run_again():
-    """a small workspace: the N-rich queries do not fit the first pass's share and finish in a later pass with a larger one"""
+def test_queries_that_find_the_pool_empty_are_run_again():
+    """a small workspace (13 chunks of 2 MB; the widest queries need 10): four queries in flight exhaust the pool, the ones that find
+    it empty give their chunks back and finish in a later pass with fewer blocks"""
     ref = F.random_acgt(6000, 17)
-    seqs = F.unaligned_queries(ref, 64, 18, n_runs=(90, 75, 350), run_prob=0.7)
-    with align.Aligner(ref, workspace_bytes=64 << 20, max_blocks=64) as al:
+    seqs = F.unaligned_queries(ref, 24, 18, n_runs=(90, 75, 1200), run_prob=0.9)
+    with align.Aligner(ref, workspace_bytes=26 << 20, max_blocks=8) as al:
         _check(ref, seqs, al)
         assert al.stats()["passes"] >= 2
 

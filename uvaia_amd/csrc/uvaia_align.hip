@@ -6,18 +6,19 @@
 // (Marco-Sola et al. 2021) as oracle/wfa_oracle.h states it, and this file reproduces that statement bit for bit.
 //
 // Design ("uvaialign"):
-//   * one wavefront (64 lanes) per query, persistent: a block takes the next query from an atomic counter until none is left.
-//     The work of one query is a chain of a few thousand dependent steps (one per score), each a handful of cells wide most of
-//     the time: throughput comes from thousands of queries in flight, not from width.  No barrier between waves, no LDS tiles.
-//   * lane = diagonal.  A step computes I, D, M of 64 diagonals at a time from the wavefronts of score - e, score - o - e,
+//   * one block of four waves per query, persistent: a block takes the next query from an atomic counter until none is left.
+//     A query is a chain of thousands of dependent steps (one per score); N-rich sequences (the normal SARS-CoV-2 case) make
+//     the wavefronts 1 000-2 000 diagonals wide for most of them, so a step has work for 256 lanes and one barrier.
+//   * lane = diagonal.  A step computes I, D, M of 256 diagonals at a time from the wavefronts of score - e, score - o - e,
 //     score - x, extends M along the diagonal in registers (byte compares; long runs are extended by the whole wave, 256
-//     characters per round trip) and stores the three offsets once.  Reference and queries are read through L2.
-//   * every wavefront stays in the block's share of the workspace (the backtrace needs all of them); a ring of the last 64
-//     headers lives in LDS so that a step finds its three source wavefronts without a trip to memory.
-//   * the backtrace runs on the same wave right after the last step and writes the projected row (ref_len characters)
-//     directly: match runs are copied 64 characters at a time, the five candidate predecessors of a step are fetched by
-//     five lanes at once.
-//   * a query that needs more wavefront memory than the block's share is flagged and run again with a larger share.
+//     characters per round trip) and stores M once.  Reference and queries are read through L2.
+//   * what is kept for the backtrace is 5 bytes per cell, not 12: the M offset and one provenance byte (which of the five
+//     predecessors gave the maximum, in the backtrace's tie order; whether the I and the D cell extend or open).  I and D
+//     offsets only feed the next e scores and live in a ring chunk.  A ring of the last 64 headers lives in LDS.
+//   * wavefront memory comes in chunks from a pool shared by the blocks in flight (a query takes what its score needs: 2 MB
+//     to more than 1 GB); a query that finds the pool empty is flagged and run again in a later, less crowded pass.
+//   * the backtrace runs on wave 0 right after the last step and writes the projected row (ref_len characters) directly:
+//     match runs are copied 64 characters at a time, runs of mismatches (N runs) are taken 63 steps per round trip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -33,70 +34,117 @@
 namespace {
 
 constexpr int WFA_NULL = -10;            // offset of a diagonal a wavefront does not hold (oracle/wfa_oracle.c)
+constexpr int NW = 4;                    // waves per block = per query
+constexpr int TPB = 64 * NW;
 constexpr int RING = 64;                 // scores whose headers stay in LDS; penalties are below this
-constexpr int HDR_INTS = 8;              // per score, at the end of the block's share, growing downwards
-enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3 };
+constexpr int HDR_INTS = 8;
+constexpr int HDR_PAGE_SCORES = 2048;    // headers of all scores live in pages of the query's own memory (the backtrace reads them)
+constexpr int MAX_HDR_PAGES = 256;
+constexpr int MAX_OWN = 1024;            // chunks a query may hold on top of the block's two permanent ones
+enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3, ST_TOOWIDE = 4 };
+enum { C_DEL_EXT = 0, C_DEL_OPEN = 1, C_INS_EXT = 2, C_INS_OPEN = 3, C_MISMATCH = 4, C_I_EXT = 8, C_D_EXT = 16 };
 
 struct WfaParams { int x, oe, e, min_wf_len, max_dist_thr, max_score; };
 
-// header of the wavefronts of one score: the three arrays share their limits (the reduction trims M and hands its limits to
-// I and D); flags bit 0 = M exists, bit 1 = I, bit 2 = D; arrays of w = hi_base - lo_base + 1 offsets at word `off`: M, then I, then D
-struct Hdr { int lo, hi, lo_base, flags; uint32_t off; int w; };
+// Workspace: chunks of 2^chunk_log2 words handed out from a stack under a spin lock (one thread of a block at a time, the others
+// wait at a barrier; a query takes a chunk every few hundred thousand cells).  Block b owns chunks 2b (first history chunk) and
+// 2b + 1 (ring of the I and D wavefronts) for the whole launch.
+struct PoolCtl { int lock, top, n_chunks, chunk_log2; };
 
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Header of the wavefronts of one score.  M, I and D share their limits (the reduction trims M and hands its limits to I and D).
+// flags bit 0 = M exists, bit 1 = I, bit 2 = D.  off16 / id16: where the arrays start, in units of 16 words from the pool's base:
+// history = M offsets (w words, padded to 16) followed by one provenance byte per cell; I and D (w16 words each) in the ring chunk.
+struct Hdr { int lo, hi, lo_base, flags; uint32_t off16; int w; uint32_t id16; };
 
-__device__ __forceinline__ int fetch(const uint32_t *A, const Hdr &h, int which, int k)
-{ // which: 0 = M, 1 = I, 2 = D.  A missing wavefront or a diagonal outside its limits gives the null offset
-  if (!((h.flags >> which) & 1) || k < h.lo || k > h.hi) return WFA_NULL;
-  const int slot = which == 0 ? 0 : (which == 1 ? 1 : ((h.flags >> 1) & 1) + 1);
-  return (int)A[h.off + (uint32_t)slot * (uint32_t)h.w + (uint32_t)(k - h.lo_base)];
-}
+__device__ __forceinline__ int w16_of(int w) { return (w + 15) & ~15; }
+__device__ __forceinline__ bool in_range(const Hdr &h, int bit, int k) { return ((h.flags >> bit) & 1) && k >= h.lo && k <= h.hi; }
+__device__ __forceinline__ int dist_to_end(int plen, int tlen, int offset, int k) { return max(plen - (offset - k), tlen - offset); }
 
-__device__ __forceinline__ int dist_to_end(int plen, int tlen, int offset, int k)
-{
-  return max(plen - (offset - k), tlen - offset);
-}
+__device__ __forceinline__ void pool_lock(PoolCtl *c) { while (atomicCAS(&c->lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4); __threadfence(); }
+__device__ __forceinline__ void pool_unlock(PoolCtl *c) { __threadfence(); atomicExch(&c->lock, 0); }
 
-__global__ __launch_bounds__(64) void wfa_align_kernel(const uint8_t *__restrict__ ref, int plen, const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off,
-                                                        const int *__restrict__ todo, int n_todo, uint8_t *__restrict__ aln, size_t aln_pitch, int *__restrict__ score_out,
-                                                        int *__restrict__ status_out, unsigned long long *__restrict__ cells_out, uint32_t *__restrict__ arena,
-                                                        unsigned long long share_words, int *next_query, WfaParams P)
+__global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restrict__ ref, int plen, const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off,
+                                                         const int *__restrict__ todo, int n_todo, uint8_t *__restrict__ aln, size_t aln_pitch, int *__restrict__ score_out,
+                                                         int *__restrict__ status_out, unsigned long long *__restrict__ cells_out, uint32_t *__restrict__ pool,
+                                                         PoolCtl *ctl, int *stack, int *next_query, WfaParams P)
 {
   __shared__ int ring[RING][HDR_INTS];
-  const int lane = threadIdx.x;
-  uint32_t *A = arena + (size_t)blockIdx.x * share_words;
-  int *H = reinterpret_cast<int *>(A + share_words);          // header of score s: H - (s + 1) * HDR_INTS
+  __shared__ int own[MAX_OWN];
+  __shared__ uint32_t hdr_page[MAX_HDR_PAGES];
+  __shared__ int wsync[2][NW][2];
+  __shared__ int bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk_log2 = ctl->chunk_log2;
+  const unsigned chunk_words = 1u << chunk_log2;
+  const size_t home_base = (size_t)(2 * blockIdx.x) << chunk_log2, ring_base = (size_t)(2 * blockIdx.x + 1) << chunk_log2;
   unsigned long long cells_total = 0;
 
   for (;;) {
-    int qi = 0;
-    if (lane == 0) qi = atomicAdd(next_query, 1);
-    qi = rfl(qi);
-    if (qi >= n_todo) break;                                  // every wave reaches this: the counter only grows
+    if (tid == 0) bc[0] = atomicAdd(next_query, 1);
+    __syncthreads();
+    const int qi = bc[0];
+    if (qi >= n_todo) break;                                  // every wave of every block reaches this: the counter only grows
     const int q = todo ? todo[qi] : qi;
     const uint8_t *text = seqs + seq_off[q];
     const int tlen = (int)(seq_off[q + 1] - seq_off[q]);
     const int alignment_k = tlen - plen;
     uint8_t *row = aln + (size_t)q * aln_pitch;
 
-    for (int i = lane; i < RING * HDR_INTS; i += 64) (&ring[0][0])[i] = 0;
+    for (int i = tid; i < RING * HDR_INTS; i += TPB) (&ring[0][0])[i] = 0;
     __syncthreads();
 
-    unsigned long long used = 0, cells = 0;                    // words of the share taken by offsets
-    int score = 0, status = ST_OK;
+    // bump allocation inside the current chunk; every thread keeps the same state
+    size_t cur_base = home_base;
+    unsigned cur_used = 0, ring_pos = 0, widest16 = 16;
+    int n_own = 0;
+    unsigned long long cells = 0;
+    int score = 0, status = ST_OK, step = 0;
     bool reached = false;
+
+    auto take = [&](unsigned words, size_t &at) -> bool {    // `words` (a multiple of 16, at most a chunk) of the query's memory; false = the pool is empty
+      if (cur_used + words > chunk_words) {
+        __syncthreads();
+        if (tid == 0) {
+          int id = -1;
+          if (n_own < MAX_OWN) {
+            pool_lock(ctl);
+            const int top = atomicAdd(&ctl->top, 0);
+            if (top > 0) { id = atomicAdd(&stack[top - 1], 0); atomicExch(&ctl->top, top - 1); }
+            pool_unlock(ctl);
+            if (id >= 0) own[n_own] = id;
+          }
+          bc[1] = id;
+        }
+        __syncthreads();
+        const int id = bc[1];
+        if (id < 0) return false;
+        n_own++;
+        cur_base = (size_t)id << chunk_log2; cur_used = 0;
+      }
+      at = cur_base + cur_used;
+      cur_used += words;
+      return true;
+    };
+
     // ---------------- forward: one step per score ----------------
     for (;;) {
-      // source wavefronts (paper eq. 3): M of score - x, M of score - o - e, I and D of score - e
+      if ((score & (HDR_PAGE_SCORES - 1)) == 0) {               // a new page of headers
+        const int page = score / HDR_PAGE_SCORES;
+        size_t at = 0;
+        if (page >= MAX_HDR_PAGES) { status = ST_MAXSCORE; break; }
+        if (!take(HDR_PAGE_SCORES * HDR_INTS, at)) { status = ST_OVERFLOW; break; }
+        if (tid == 0) hdr_page[page] = (uint32_t)(at >> 4);
+        __syncthreads();
+      }
       Hdr hs{}, hg{}, he{};
       bool have = false;
       int lo = 0, hi = 0;
-      if (score == 0) { have = true; }
+      if (score == 0) have = true;
       else {
         auto load = [&](int s, Hdr &h) {
           if (s < 0) { h.flags = 0; return; }
           const int *r = ring[s & (RING - 1)];
-          h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off = (uint32_t)r[4]; h.w = r[5];
+          h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off16 = (uint32_t)r[4]; h.w = r[5]; h.id16 = (uint32_t)r[6];
         };
         load(score - P.x, hs); load(score - P.oe, hg); load(score - P.e, he);
         const bool n_sub = !(hs.flags & 1), n_gap = !(hg.flags & 1), n_i = !(he.flags & 2), n_d = !(he.flags & 4);
@@ -106,32 +154,47 @@ __global__ __launch_bounds__(64) void wfa_align_kernel(const uint8_t *__restrict
           hi = max(max(n_sub ? -1 : hs.hi, n_gap ? -1 : hg.hi), max(n_i ? -1 : he.hi, n_d ? -1 : he.hi)) + 1;
         }
       }
-      const size_t hdr_words = (size_t)(score + 1) * HDR_INTS;
-      if (used + hdr_words > share_words) { status = ST_OVERFLOW; break; }
-      int *hdr_out = H - (size_t)(score + 1) * HDR_INTS;
+      int *hdr_out = reinterpret_cast<int *>(pool + ((size_t)hdr_page[score / HDR_PAGE_SCORES] << 4)) + (size_t)(score & (HDR_PAGE_SCORES - 1)) * HDR_INTS;
       int *ring_out = ring[score & (RING - 1)];
       if (!have) {
-        if (lane < HDR_INTS) { ring_out[lane] = 0; hdr_out[lane] = 0; }
+        // every wave writes the (identical) ring entry it is going to read: no barrier for it; the header in memory is for the backtrace
+        if (lane < HDR_INTS) { ring_out[lane] = 0; if (wave == 0) hdr_out[lane] = 0; }
       } else {
         const bool has_i = score > 0 && ((hg.flags & 1) || (he.flags & 2)), has_d = score > 0 && ((hg.flags & 1) || (he.flags & 4));
-        const int w = hi - lo + 1;
-        const size_t need = (size_t)w * (1 + (has_i ? 1 : 0) + (has_d ? 1 : 0));
-        if (used + need + hdr_words > share_words) { status = ST_OVERFLOW; break; }
-        const uint32_t off = (uint32_t)used;
-        used += need; cells += (unsigned)w;
-        uint32_t *out_m = A + off, *out_i = out_m + w, *out_d = out_m + (size_t)w * (has_i ? 2 : 1);
+        const int w = hi - lo + 1, w16 = w16_of(w);
+        const unsigned hist_words = (unsigned)w16 + (unsigned)w16_of((w + 3) / 4);
+        // the ring chunk keeps the I and D wavefronts of the last e + 1 steps: e + 2 pairs of the widest one must fit (one is lost to the wrap)
+        widest16 = max(widest16, (unsigned)w16);
+        if ((unsigned long long)(P.e + 2) * 2ull * widest16 > chunk_words || hist_words > chunk_words) { status = ST_TOOWIDE; break; }
+        size_t m_at = 0;
+        if (!take(hist_words, m_at)) { status = ST_OVERFLOW; break; }
+        if (ring_pos + 2u * (unsigned)w16 > chunk_words) ring_pos = 0;
+        const size_t id_at = ring_base + ring_pos;
+        ring_pos += 2u * (unsigned)w16;
+        cells += (unsigned)w;
+        uint32_t *out_m = pool + m_at, *out_i = pool + id_at, *out_d = out_i + w16;
+        uint8_t *out_c = reinterpret_cast<uint8_t *>(out_m + w16);
+        const uint32_t *ms = pool + ((size_t)hs.off16 << 4) - hs.lo_base, *mg = pool + ((size_t)hg.off16 << 4) - hg.lo_base;
+        const uint32_t *ie = pool + ((size_t)he.id16 << 4) - he.lo_base, *de = ie + w16_of(he.w);
         int min_distance = max(plen, tlen);
         bool hit_end = false;
-        for (int k0 = lo; k0 <= hi; k0 += 64) {
+        for (int k0 = lo + 64 * wave; k0 <= hi; k0 += TPB) {
           const int k = k0 + lane;
           const bool act = k <= hi;
           int m = 0;
+          unsigned code = C_MISMATCH;
           if (score > 0) {
-            int sub = fetch(A, hs, 0, k);
-            if ((hs.flags & 1) && k >= hs.lo && k <= hs.hi) sub++;        // the + 1 belongs to a fetched value only
-            m = sub;
-            if (has_i) { const int ins = max(fetch(A, hg, 0, k - 1), fetch(A, he, 1, k - 1)) + 1; if (act) out_i[k - lo] = (uint32_t)ins; m = max(m, ins); }
-            if (has_d) { const int del = max(fetch(A, hg, 0, k + 1), fetch(A, he, 2, k + 1));     if (act) out_d[k - lo] = (uint32_t)del; m = max(m, del); }
+            const bool in_s = in_range(hs, 0, k), in_gm = in_range(hg, 0, k - 1), in_gp = in_range(hg, 0, k + 1), in_i = in_range(he, 1, k - 1), in_d = in_range(he, 2, k + 1);
+            const int r_s = in_s ? (int)ms[k] : WFA_NULL, r_gm = in_gm ? (int)mg[k - 1] : WFA_NULL, r_gp = in_gp ? (int)mg[k + 1] : WFA_NULL;
+            const int r_i = in_i ? (int)ie[k - 1] : WFA_NULL, r_d = in_d ? (int)de[k + 1] : WFA_NULL;
+            // the five predecessors as the backtrace sees them (a "+ 1" belongs to a fetched value only)
+            const int v_sub = in_s ? r_s + 1 : WFA_NULL, v_io = in_gm ? r_gm + 1 : WFA_NULL, v_ie = in_i ? r_i + 1 : WFA_NULL, v_do = r_gp, v_de = r_d;
+            m = v_sub;
+            if (has_i) { const int ins = max(r_gm, r_i) + 1; if (act) out_i[k - lo] = (uint32_t)ins; m = max(m, ins); }
+            if (has_d) { const int del = max(r_gp, r_d);     if (act) out_d[k - lo] = (uint32_t)del; m = max(m, del); }
+            const int bt = max(v_sub, max(max(v_io, v_ie), max(v_do, v_de)));
+            code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
+            code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
           }
           // exact extension along the diagonal (paper algorithm 2): a few characters per lane, long runs by the whole wave
           int v = m - k, h = m;
@@ -164,17 +227,24 @@ __global__ __launch_bounds__(64) void wfa_align_kernel(const uint8_t *__restrict
           }
           if (act) {
             out_m[k - lo] = (uint32_t)m;
+            out_c[k - lo] = (uint8_t)code;
             min_distance = min(min_distance, dist_to_end(plen, tlen, m, k));
             if (k == alignment_k && m >= tlen) hit_end = true;
           }
         }
-        reached = __any(hit_end);
-        __syncthreads();                                        // the offsets just stored are read by other lanes from here on
-        // adaptive reduction (paper section 2.4): trim both ends of a long wavefront, never across the end cell's diagonal
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) min_distance = min(min_distance, __shfl_xor(min_distance, o));
+        const bool wave_hit = __any(hit_end);
+        if (lane == 0) { wsync[step & 1][wave][0] = min_distance; wsync[step & 1][wave][1] = wave_hit ? 1 : 0; }
+        __syncthreads();                                        // the one barrier of a step: offsets stored by other waves are read from here on
+        min_distance = wsync[step & 1][0][0]; reached = wsync[step & 1][0][1] != 0;
+#pragma unroll
+        for (int u = 1; u < NW; u++) { min_distance = min(min_distance, wsync[step & 1][u][0]); reached = reached || wsync[step & 1][u][1] != 0; }
+        step++;
+        // adaptive reduction (paper section 2.4): trim both ends of a long wavefront, never across the end cell's diagonal.
+        // Every wave computes the same limits for itself.
         int rlo = lo, rhi = hi;
         if (P.min_wf_len > 0 && w >= P.min_wf_len) {
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) min_distance = min(min_distance, __shfl_xor(min_distance, o));
           const int top_limit = min(alignment_k - 1, hi);
           if (lo < top_limit) {
             rlo = top_limit;
@@ -198,72 +268,115 @@ __global__ __launch_bounds__(64) void wfa_align_kernel(const uint8_t *__restrict
         }
         if (lane < HDR_INTS) {
           const int flags = 1 | (has_i ? 2 : 0) | (has_d ? 4 : 0);
-          const int val = lane == 0 ? rlo : lane == 1 ? rhi : lane == 2 ? lo : lane == 3 ? flags : lane == 4 ? (int)off : lane == 5 ? w : 0;
-          ring_out[lane] = val; hdr_out[lane] = val;
+          const int val = lane == 0 ? rlo : lane == 1 ? rhi : lane == 2 ? lo : lane == 3 ? flags : lane == 4 ? (int)(uint32_t)(m_at >> 4) : lane == 5 ? w : lane == 6 ? (int)(uint32_t)(id_at >> 4) : 0;
+          ring_out[lane] = val;
+          if (wave == 0) hdr_out[lane] = val;
         }
       }
-      __syncthreads();                                          // ring entry visible to every lane
       if (reached) break;
       score++;
       if (score > P.max_score) { status = ST_MAXSCORE; break; }
     }
-    // ---------------- backtrace + projection on the reference's columns (src/align.c:366-390) ----------------
-    if (status == ST_OK) {
+    __syncthreads();                                            // headers in memory, last offsets: visible to the backtrace
+    // ---------------- backtrace + projection on the reference's columns (src/align.c:366-390): wave 0 ----------------
+    if (status == ST_OK && wave == 0) {
       auto hdr_of = [&](int s, Hdr &h) {
-        const int *r = H - (size_t)(s + 1) * HDR_INTS;
-        h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off = (uint32_t)r[4]; h.w = r[5];
+        const int *r = reinterpret_cast<const int *>(pool + ((size_t)hdr_page[s / HDR_PAGE_SCORES] << 4)) + (size_t)(s & (HDR_PAGE_SCORES - 1)) * HDR_INTS;
+        h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off16 = (uint32_t)r[4]; h.w = r[5];
       };
-      int s = score, k = alignment_k, type = 0;               // type: 0 = M, 1 = I, 2 = D
-      Hdr hf; hdr_of(s, hf);
-      int offset = fetch(A, hf, 0, k);
+      auto m_of = [&](const Hdr &h, int k) { return (int)pool[((size_t)h.off16 << 4) + (size_t)(k - h.lo_base)]; };
+      auto code_of = [&](const Hdr &h, int k) { return (int)reinterpret_cast<const uint8_t *>(pool + ((size_t)h.off16 << 4) + w16_of(h.w))[k - h.lo_base]; };
+      auto cell_ok = [&](const Hdr &h, int k) { return (h.flags & 1) && k >= h.lo_base && k < h.lo_base + h.w; };
+      int s = score, k = alignment_k, state = 0;              // state: 0 = M, 1 = I, 2 = D
+      Hdr hc; hdr_of(s, hc);
+      int offset = in_range(hc, 0, k) ? m_of(hc, k) : WFA_NULL;
       int v = offset - k, h = offset;
       bool broken = false;
       while (v > 0 && h > 0 && s > 0) {
-        const int s_oe = s - P.oe, s_e = s - P.e, s_x = s - P.x;
-        // lane 0: deletion extend, 1: deletion open, 2: insertion extend, 3: insertion open, 4: mismatch
-        int val = WFA_NULL;
-        if (lane < 5) {
-          const int src = (lane == 0 || lane == 2) ? s_e : (lane == 4 ? s_x : s_oe);
-          const int which = lane == 0 ? 2 : (lane == 2 ? 1 : 0);
-          const int kk = lane < 2 ? k + 1 : (lane < 4 ? k - 1 : k);
-          const bool allowed = lane < 2 ? type != 1 : (lane < 4 ? type != 2 : type == 0);
-          if (allowed && src >= 0) {
-            Hdr hh; hdr_of(src, hh);
-            if (((hh.flags >> which) & 1) && kk >= hh.lo && kk <= hh.hi) val = fetch(A, hh, which, kk) + (lane >= 2 ? 1 : 0);
+        if (state == 0) {
+          // A run of mismatches on one diagonal with no matches between them (an N run of the query): lane j looks at the cell
+          // j mismatches back; the leading lanes whose cell came from a mismatch and was not extended are taken in one go.
+          const int sj = s - lane * P.x;
+          int cj = -1, mj = WFA_NULL;
+          if (sj >= 0) { Hdr hj; hdr_of(sj, hj); if (in_range(hj, 0, k)) { mj = m_of(hj, k); cj = code_of(hj, k) & 7; } }
+          const int mnext = __shfl_down(mj, 1);
+          const bool pure = lane < 63 && sj > 0 && cj == C_MISMATCH && mnext != WFA_NULL && mj == mnext + 1 && v - lane > 0 && h - lane > 0;
+          const unsigned long long np = ~__ballot(pure);
+          const int n = np ? __builtin_ctzll(np) : 63;
+          if (n > 0) {
+            if (lane < n && v - 1 - lane <= plen) row[v - 1 - lane] = text[h - 1 - lane];
+            s -= n * P.x; offset -= n; v -= n; h -= n;
+            continue;
           }
-        }
-        const int del_ext = __shfl(val, 0), del_open = __shfl(val, 1), ins_ext = __shfl(val, 2), ins_open = __shfl(val, 3), misms = __shfl(val, 4);
-        const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
-        if (type == 0) {
+          const int c = __shfl(cj, 0);
+          if (c < 0) { broken = true; break; }
+          int max_all = WFA_NULL;
+          if (c == C_MISMATCH) { const int mn = __shfl(mj, 1); if (mn == WFA_NULL) { broken = true; break; } max_all = mn + 1; }
+          else if (c == C_INS_OPEN || c == C_DEL_OPEN) {
+            const int ss = s - P.oe, kk = c == C_INS_OPEN ? k - 1 : k + 1;
+            Hdr ho; if (ss < 0) { broken = true; break; } hdr_of(ss, ho);
+            if (!in_range(ho, 0, kk)) { broken = true; break; }
+            max_all = m_of(ho, kk) + (c == C_INS_OPEN ? 1 : 0);
+          } else {                                               // a gap being extended: follow it to the M cell it was opened from
+            const int dk = c == C_INS_EXT ? -1 : 1, bit = c == C_INS_EXT ? C_I_EXT : C_D_EXT;
+            int ss = s - P.e, kk = k + dk, cnt = 0;
+            for (;;) {
+              Hdr hw; if (ss < 0) { broken = true; break; } hdr_of(ss, hw);
+              if (!cell_ok(hw, kk)) { broken = true; break; }
+              cnt++;
+              if (!(code_of(hw, kk) & bit)) {
+                Hdr ho; if (ss - P.oe < 0) { broken = true; break; } hdr_of(ss - P.oe, ho);
+                if (!in_range(ho, 0, kk + dk)) { broken = true; break; }
+                max_all = m_of(ho, kk + dk) + (c == C_INS_EXT ? cnt + 1 : 0);
+                break;
+              }
+              ss -= P.e; kk += dk;
+            }
+            if (broken) break;
+          }
           const int nm = offset - max_all;
           if (nm < 0 || (nm > 0 && (max_all < 0 || max_all - k < 0 || v > plen + 1 || h > tlen + 1))) { broken = true; break; }   // (a consistent backtrace never gets here)
           bool bad = false;
           for (int j0 = 0; j0 < nm; j0 += 64) {
             const int j = j0 + lane;
-            if (j < nm) { const uint8_t c = text[h - 1 - j]; if (c != ref[v - 1 - j]) bad = true; row[v - 1 - j] = c; }
+            if (j < nm) { const uint8_t ch = text[h - 1 - j]; if (ch != ref[v - 1 - j]) bad = true; row[v - 1 - j] = ch; }
           }
           if (__any(bad)) { broken = true; break; }
           offset = max_all;
           v = offset - k; h = offset;
+          if (c == C_DEL_EXT)        { if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s -= P.e;  k++; state = 2; }
+          else if (c == C_DEL_OPEN)  { if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s -= P.oe; k++; state = 0; }
+          else if (c == C_INS_EXT)   { s -= P.e;  k--; offset--; state = 1; }
+          else if (c == C_INS_OPEN)  { s -= P.oe; k--; offset--; state = 0; }
+          else                       { if (lane == 0 && v > 0 && h > 0 && v <= plen + 1) row[v - 1] = text[h - 1]; s -= P.x; offset--; }
+        } else {
+          Hdr hw; hdr_of(s, hw);
+          if (!cell_ok(hw, k)) { broken = true; break; }
+          const int cb = code_of(hw, k);
+          if (state == 1) { const bool ext = cb & C_I_EXT; s -= ext ? P.e : P.oe; k--; offset--; state = ext ? 1 : 0; }
+          else { const bool ext = cb & C_D_EXT; if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s -= ext ? P.e : P.oe; k++; state = ext ? 2 : 0; }
         }
-        if (max_all == del_ext)       { if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s = s_e;  k++; type = 2; }
-        else if (max_all == del_open) { if (lane == 0 && v > 0 && v <= plen) row[v - 1] = '-'; s = s_oe; k++; type = 0; }
-        else if (max_all == ins_ext)  { s = s_e;  k--; offset--; type = 1; }
-        else if (max_all == ins_open) { s = s_oe; k--; offset--; type = 0; }
-        else if (max_all == misms)    { if (lane == 0 && v > 0 && h > 0 && v <= plen + 1) row[v - 1] = text[h - 1]; s = s_x; offset--; }
-        else { broken = true; break; }
         v = offset - k; h = offset;
       }
-      if (broken) status = ST_BACKTRACE;
+      if (broken || s < 0) status = ST_BACKTRACE;
       else if (s == 0) { for (int j = lane; j < min(v, plen); j += 64) row[j] = text[j]; }      // the last stroke of matches (k = 0 at score 0)
       else { for (int j = lane; j < min(v, plen); j += 64) row[j] = '-'; }                      // leading deletions; leading insertions leave no trace
       if (lane == 0) row[plen] = 0;
     }
-    if (lane == 0) { score_out[q] = status == ST_OK ? score : -1; status_out[q] = status; }
+    if (tid == 0) {
+      score_out[q] = status == ST_OK ? score : -1; status_out[q] = status;     // (thread 0 belongs to the wave that ran the backtrace)
+      if (n_own > 0) {                                           // the chunks taken for this query go back
+        pool_lock(ctl);
+        int top = atomicAdd(&ctl->top, 0);
+        for (int i = 0; i < n_own; i++) atomicExch(&stack[top++], own[i]);
+        atomicExch(&ctl->top, top);
+        pool_unlock(ctl);
+      }
+    }
     cells_total += cells;
     __syncthreads();
   }
-  if (lane == 0 && cells_total) atomicAdd(cells_out, cells_total);
+  if (tid == 0 && cells_total) atomicAdd(cells_out, cells_total);
 }
 
 thread_local std::string g_align_open_error;
@@ -279,8 +392,11 @@ struct uvaia_aligner {
   long long *d_off = nullptr;
   int *d_score = nullptr, *d_status = nullptr, *d_next = nullptr, *d_todo = nullptr;
   unsigned long long *d_cells = nullptr;
-  uint32_t *d_arena = nullptr;
-  size_t seqs_cap = 0, n_cap = 0, arena_words = 0, workspace_request = 0;
+  uint32_t *d_pool = nullptr;               // wavefront memory: n_chunks chunks of 2^chunk_log2 words
+  PoolCtl *d_ctl = nullptr; int *d_stack = nullptr;
+  int n_chunks = 0, chunk_log2 = 0;
+  std::vector<int> h_stack;
+  size_t seqs_cap = 0, n_cap = 0, workspace_request = 0;
   int n = 0, max_blocks = 0, passes = 0;
   bool ran = false;
   unsigned long long cells = 0;
@@ -325,15 +441,27 @@ int ensure_pool(uvaia_aligner *a, size_t bytes, int n)
   return 0;
 }
 
-int ensure_arena(uvaia_aligner *a)
+int ensure_pool_memory(uvaia_aligner *a)
 {
-  if (a->d_arena) return 0;
+  if (a->d_pool) return 0;
+  // a chunk holds the ring of I and D wavefronts (e + 2 pairs of the widest wavefront, at most all plen + tlen + 1 diagonals of a
+  // query of up to 1.5 reference lengths, src/align.c:199) and serves as the unit the queries' histories grow by
+  const unsigned long long widest = (unsigned long long)a->plen * 5 / 2 + 64;
+  int lg = 19;
+  while ((1ull << lg) < (unsigned long long)(a->P.e + 2) * 2ull * widest) lg++;
+  if (lg > 28) return afail(a, UVAIA_ALIGN_EINVAL, "reference of %d sites is too long for the wavefront workspace", a->plen);
+  const size_t chunk_bytes = (size_t)4 << lg;
   size_t free_b = 0, total_b = 0;
   ACHK(a, hipMemGetInfo(&free_b, &total_b));
-  size_t want = a->workspace_request ? a->workspace_request : std::min<size_t>(free_b / 2, (size_t)a->max_blocks * (24u << 20));
-  want = std::max<size_t>(want, 64u << 20) / 4096 * 4096;
-  ACHK(a, hipMalloc(&a->d_arena, want));
-  a->arena_words = want / sizeof(uint32_t);
+  size_t want = a->workspace_request ? a->workspace_request : free_b / 4 * 3;
+  want = std::min(want, (size_t)0xffffffffull * 64);              // array positions are kept in units of 64 bytes in 32 bits
+  size_t n_chunks = want / chunk_bytes;
+  if (n_chunks < 3) return afail(a, UVAIA_ALIGN_ENOMEM, "workspace of %zu bytes is below three chunks of %zu bytes", want, chunk_bytes);
+  ACHK(a, hipMalloc(&a->d_pool, n_chunks * chunk_bytes));
+  ACHK(a, hipMalloc(&a->d_ctl, sizeof(PoolCtl)));
+  ACHK(a, hipMalloc(&a->d_stack, n_chunks * sizeof(int)));
+  a->n_chunks = (int)n_chunks; a->chunk_log2 = lg;
+  a->h_stack.resize(n_chunks);
   return 0;
 }
 
@@ -357,7 +485,7 @@ void uvaia_align_close(uvaia_aligner *a)
   hipSetDevice(a->device);
   if (a->stream) hipStreamSynchronize(a->stream);
   hipFree(a->d_ref); hipFree(a->d_seqs); hipFree(a->d_aln); hipFree(a->d_off); hipFree(a->d_score); hipFree(a->d_status); hipFree(a->d_next);
-  hipFree(a->d_todo); hipFree(a->d_cells); hipFree(a->d_arena);
+  hipFree(a->d_todo); hipFree(a->d_cells); hipFree(a->d_pool); hipFree(a->d_ctl); hipFree(a->d_stack);
   if (a->ev_a) hipEventDestroy(a->ev_a);
   if (a->ev_b) hipEventDestroy(a->ev_b);
   if (a->stream) hipStreamDestroy(a->stream);
@@ -388,7 +516,11 @@ int uvaia_align_open(uvaia_aligner **out, const char *ref, int ref_len, int devi
   const long long ms = (long long)ref_len * opt.mismatch + opt.gap_opening + 2LL * ref_len * opt.gap_extension;
   a->P.max_score = (int)std::min<long long>(ms, 0x3fffffff);
   a->workspace_request = opt.workspace_bytes;
-  a->max_blocks = opt.max_blocks > 0 ? opt.max_blocks : prop.multiProcessorCount * 32;      // eight waves per SIMD
+  {   // as many blocks as the chip holds at once (the blocks are persistent: more would only queue behind them)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wfa_align_kernel, TPB, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    a->max_blocks = opt.max_blocks > 0 ? opt.max_blocks : prop.multiProcessorCount * per_cu;
+  }
 #define OCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = afail(nullptr, e_ == hipErrorOutOfMemory ? UVAIA_ALIGN_ENOMEM : UVAIA_ALIGN_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); uvaia_align_close(a); return rc_; } } while (0)
   OCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
   OCHK(hipEventCreate(&a->ev_a)); OCHK(hipEventCreate(&a->ev_b));
@@ -438,18 +570,22 @@ int uvaia_align_run(uvaia_aligner *a)
   ACHK(a, hipSetDevice(a->device));
   a->passes = 0; a->cells = 0; a->kernel_ms = 0; a->ran = false;
   if (a->n == 0) { a->ran = true; return 0; }
-  int rc = ensure_arena(a); if (rc) return rc;
+  int rc = ensure_pool_memory(a); if (rc) return rc;
   ACHK(a, hipMemsetAsync(a->d_cells, 0, sizeof(unsigned long long), a->stream));
   ACHK(a, hipEventRecord(a->ev_a, a->stream));
-  int n_todo = a->n, blocks = std::min(a->n, a->max_blocks);
+  // every block keeps two chunks for the whole launch; the rest of the pool is what the queries in flight share
+  int n_todo = a->n, blocks = std::max(1, std::min(std::min(a->n, a->max_blocks), a->n_chunks / 3));
   const int *todo = nullptr;
   std::vector<int> status((size_t)a->n), list;
   for (;;) {
-    const unsigned long long share = (unsigned long long)(a->arena_words / (size_t)blocks) / 16 * 16;
-    if (share < 1024) return afail(a, UVAIA_ALIGN_ENOMEM, "workspace of %zu bytes is too small for %d queries in flight", a->arena_words * 4, blocks);
+    const PoolCtl ctl{0, a->n_chunks - 2 * blocks, a->n_chunks, a->chunk_log2};
+    for (int i = 0; i < ctl.top; i++) a->h_stack[(size_t)i] = 2 * blocks + i;
+    ACHK(a, hipMemcpyAsync(a->d_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice, a->stream));
+    if (ctl.top > 0) ACHK(a, hipMemcpyAsync(a->d_stack, a->h_stack.data(), (size_t)ctl.top * sizeof(int), hipMemcpyHostToDevice, a->stream));
     ACHK(a, hipMemsetAsync(a->d_next, 0, sizeof(int), a->stream));
-    hipLaunchKernelGGL(wfa_align_kernel, dim3((unsigned)blocks), dim3(64), 0, a->stream, a->d_ref, a->plen, a->d_seqs, a->d_off, todo, n_todo, a->d_aln, (size_t)a->plen + 1,
-                       a->d_score, a->d_status, a->d_cells, a->d_arena, share, a->d_next, a->P);
+    ACHK(a, hipStreamSynchronize(a->stream));                     // (ctl is on the stack of this function)
+    hipLaunchKernelGGL(wfa_align_kernel, dim3((unsigned)blocks), dim3(TPB), 0, a->stream, a->d_ref, a->plen, a->d_seqs, a->d_off, todo, n_todo, a->d_aln, (size_t)a->plen + 1,
+                       a->d_score, a->d_status, a->d_cells, a->d_pool, a->d_ctl, a->d_stack, a->d_next, a->P);
     ACHK(a, hipGetLastError());
     a->passes++;
     ACHK(a, hipMemcpyAsync(status.data(), a->d_status, (size_t)a->n * sizeof(int), hipMemcpyDeviceToHost, a->stream));
@@ -458,12 +594,14 @@ int uvaia_align_run(uvaia_aligner *a)
     for (int i = 0; i < a->n; i++) {
       if (status[(size_t)i] == ST_OVERFLOW) list.push_back(i);
       else if (status[(size_t)i] == ST_MAXSCORE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: alignment score above %d, the size of the reference's score table", i, a->P.max_score);
+      else if (status[(size_t)i] == ST_TOOWIDE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: a wavefront wider than the workspace's chunks hold (%zu bytes each)", i, (size_t)4 << a->chunk_log2);
       else if (status[(size_t)i] == ST_BACKTRACE) return afail(a, UVAIA_ALIGN_ESTATE, "sequence %d: inconsistent backtrace", i);
     }
     if (list.empty()) break;
-    if (blocks == 1) return afail(a, UVAIA_ALIGN_ENOMEM, "sequence %d needs more than the whole workspace (%zu bytes) for its wavefronts", list[0], a->arena_words * 4);
-    blocks = std::max(1, std::min((int)list.size(), blocks / 8));
+    if (blocks == 1) return afail(a, UVAIA_ALIGN_ENOMEM, "sequence %d needs more than the whole workspace (%zu bytes) for its wavefronts", list[0], ((size_t)a->n_chunks * 4) << a->chunk_log2);
+    blocks = std::max(1, std::min((int)list.size(), blocks / 4));
     ACHK(a, hipMemcpyAsync(a->d_todo, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, a->stream));
+    ACHK(a, hipStreamSynchronize(a->stream));
     todo = a->d_todo; n_todo = (int)list.size();
   }
   ACHK(a, hipEventRecord(a->ev_b, a->stream));
@@ -506,7 +644,7 @@ int uvaia_align_stats(uvaia_aligner *a, unsigned long long *cells, double *wavef
 {
   if (!a) return UVAIA_ALIGN_EINVAL;
   if (cells) *cells = a->cells;
-  if (wavefront_bytes) *wavefront_bytes = (double)a->cells * 32.0;     // three offsets written, five read per cell
+  if (wavefront_bytes) *wavefront_bytes = (double)a->cells * 33.0;     // per cell: M offset + provenance byte kept, I and D offsets to the ring, five offsets read
   if (passes) *passes = a->passes;
   if (kernel_ms) *kernel_ms = a->kernel_ms;
   return 0;

@@ -60,6 +60,14 @@ __device__ __forceinline__ int w16_of(int w) { return (w + 15) & ~15; }
 __device__ __forceinline__ bool in_range(const Hdr &h, int bit, int k) { return ((h.flags >> bit) & 1) && k >= h.lo && k <= h.hi; }
 __device__ __forceinline__ int dist_to_end(int plen, int tlen, int offset, int k) { return max(plen - (offset - k), tlen - offset); }
 
+__device__ __forceinline__ int matching_prefix8(const uint8_t *a, const uint8_t *b)
+{ // leading bytes (0..8) on which the two strings agree; the compiler picks the load width it may use for unaligned addresses
+  unsigned long long x, y;
+  __builtin_memcpy(&x, a, 8); __builtin_memcpy(&y, b, 8);
+  const unsigned long long d = x ^ y;
+  return d ? (int)(__builtin_ctzll(d) >> 3) : 8;
+}
+
 __device__ __forceinline__ void pool_lock(PoolCtl *c) { while (atomicCAS(&c->lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4); __threadfence(); }
 __device__ __forceinline__ void pool_unlock(PoolCtl *c) { __threadfence(); atomicExch(&c->lock, 0); }
 
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
   __shared__ int own[MAX_OWN];
   __shared__ uint32_t hdr_page[MAX_HDR_PAGES];
   __shared__ int wsync[2][NW][2];
+  __shared__ int dend[2][2][64];           // distance to the end cell of a wavefront's first and last 64 diagonals (for the reduction)
   __shared__ int bc[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk_log2 = ctl->chunk_log2;
@@ -196,12 +205,15 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
             code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
           }
-          // exact extension along the diagonal (paper algorithm 2): a few characters per lane, long runs by the whole wave
+          // exact extension along the diagonal (paper algorithm 2): eight characters per lane in one round trip, longer runs by the
+          // whole wave, 1 024 characters per round trip (the loads may run up to seven bytes past a sequence: both buffers are padded)
           int v = m - k, h = m;
           bool go = act && (unsigned)h < (unsigned)tlen && (unsigned)v < (unsigned)plen;
-          for (int i = 0; i < 4; i++) {
-            if (!__any(go)) break;
-            if (go) { if (ref[v] == text[h]) { v++; h++; m++; go = v < plen && h < tlen; } else go = false; }
+          if (__any(go)) {
+            int nmat = 0;
+            if (go) nmat = min(matching_prefix8(ref + v, text + h), min(plen - v, tlen - h));
+            v += nmat; h += nmat; m += nmat;
+            go = go && nmat == 8 && v < plen && h < tlen;
           }
           unsigned long long more = __ballot(go);
           while (more) {
@@ -210,25 +222,27 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             const int vj = __shfl(v, j), hj = __shfl(h, j);
             int ext = 0;
             for (;;) {
-              unsigned long long bad[4];
+              unsigned long long part[2];
+              int nm_[2];
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const int pv = vj + ext + u * 64 + lane, ph = hj + ext + u * 64 + lane;
-                const bool ok = pv < plen && ph < tlen && ref[pv] == text[ph];
-                bad[u] = __ballot(!ok);
+              for (int u = 0; u < 2; u++) {
+                const int pv = vj + ext + (u * 64 + lane) * 8, ph = hj + ext + (u * 64 + lane) * 8;
+                nm_[u] = (pv < plen && ph < tlen) ? min(matching_prefix8(ref + pv, text + ph), min(plen - pv, tlen - ph)) : 0;
+                part[u] = __ballot(nm_[u] < 8);
               }
-              if (bad[0]) { ext += __builtin_ctzll(bad[0]); break; }
-              if (bad[1]) { ext += 64 + __builtin_ctzll(bad[1]); break; }
-              if (bad[2]) { ext += 128 + __builtin_ctzll(bad[2]); break; }
-              if (bad[3]) { ext += 192 + __builtin_ctzll(bad[3]); break; }
-              ext += 256;
+              if (part[0]) { const int l = __builtin_ctzll(part[0]); ext += 8 * l + __shfl(nm_[0], l); break; }
+              if (part[1]) { const int l = __builtin_ctzll(part[1]); ext += 512 + 8 * l + __shfl(nm_[1], l); break; }
+              ext += 1024;
             }
             if (lane == j) m += ext;
           }
+          const int dk_ = act ? dist_to_end(plen, tlen, m, k) : 0x7fffffff;
+          if (k0 == lo) dend[step & 1][0][lane] = dk_;
+          if (k0 + 64 > hi) dend[step & 1][1][lane] = dk_;
           if (act) {
             out_m[k - lo] = (uint32_t)m;
             out_c[k - lo] = (uint8_t)code;
-            min_distance = min(min_distance, dist_to_end(plen, tlen, m, k));
+            min_distance = min(min_distance, dk_);
             if (k == alignment_k && m >= tlen) hit_end = true;
           }
         }
@@ -240,15 +254,18 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         min_distance = wsync[step & 1][0][0]; reached = wsync[step & 1][0][1] != 0;
 #pragma unroll
         for (int u = 1; u < NW; u++) { min_distance = min(min_distance, wsync[step & 1][u][0]); reached = reached || wsync[step & 1][u][1] != 0; }
+        const int par = step & 1;
         step++;
         // adaptive reduction (paper section 2.4): trim both ends of a long wavefront, never across the end cell's diagonal.
-        // Every wave computes the same limits for itself.
+        // Every wave computes the same limits for itself, as a rule from the two ends' distances in LDS.
         int rlo = lo, rhi = hi;
         if (P.min_wf_len > 0 && w >= P.min_wf_len) {
           const int top_limit = min(alignment_k - 1, hi);
           if (lo < top_limit) {
             rlo = top_limit;
-            for (int k0 = lo; k0 < top_limit; k0 += 64) {
+            const unsigned long long b0 = __ballot(lo + lane < top_limit && dend[par][0][lane] - min_distance <= P.max_dist_thr);
+            if (b0) rlo = lo + __builtin_ctzll(b0);
+            else for (int k0 = lo + 64; k0 < top_limit; k0 += 64) {
               const int k = k0 + lane;
               const bool keep = k < top_limit && dist_to_end(plen, tlen, (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
               const unsigned long long b = __ballot(keep);
@@ -258,7 +275,10 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
           const int bottom_limit = max(alignment_k + 1, rlo);
           if (hi > bottom_limit) {
             rhi = bottom_limit;
-            for (int k0 = hi; k0 > bottom_limit; k0 -= 64) {
+            const int kh = lo + ((hi - lo) / 64) * 64;                  // first diagonal of the chunk that holds hi
+            const unsigned long long b0 = __ballot(kh + lane <= hi && kh + lane > bottom_limit && dend[par][1][lane] - min_distance <= P.max_dist_thr);
+            if (b0) rhi = kh + 63 - __builtin_clzll(b0);
+            else for (int k0 = kh - 1; k0 > bottom_limit; k0 -= 64) {
               const int k = k0 - lane;
               const bool keep = k > bottom_limit && dist_to_end(plen, tlen, (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
               const unsigned long long b = __ballot(keep);

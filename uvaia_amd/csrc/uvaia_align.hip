@@ -34,13 +34,15 @@
 namespace {
 
 constexpr int WFA_NULL = -10;            // offset of a diagonal a wavefront does not hold (oracle/wfa_oracle.c)
-constexpr int NW = 4;                    // waves per block = per query
+constexpr int NW = 8;                    // waves per block = per query
 constexpr int TPB = 64 * NW;
 constexpr int RING = 64;                 // scores whose headers stay in LDS; penalties are below this
 constexpr int HDR_INTS = 8;
 constexpr int HDR_PAGE_SCORES = 2048;    // headers of all scores live in pages of the query's own memory (the backtrace reads them)
 constexpr int MAX_HDR_PAGES = 256;
-constexpr int MAX_OWN = 1024;            // chunks a query may hold on top of the block's two permanent ones
+constexpr int MAX_OWN = 512;             // chunks a query may hold on top of the block's two permanent ones
+constexpr int WL = 2560;                 // widest wavefront kept in LDS (16-bit offsets + 16)
+constexpr int RM = 5, RID = 2;           // LDS slots: M wavefronts of the last RM steps, I and D of the last RID
 enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3, ST_TOOWIDE = 4 };
 enum { C_DEL_EXT = 0, C_DEL_OPEN = 1, C_INS_EXT = 2, C_INS_OPEN = 3, C_MISMATCH = 4, C_I_EXT = 8, C_D_EXT = 16 };
 
@@ -54,7 +56,7 @@ struct PoolCtl { int lock, top, n_chunks, chunk_log2; };
 // Header of the wavefronts of one score.  M, I and D share their limits (the reduction trims M and hands its limits to I and D).
 // flags bit 0 = M exists, bit 1 = I, bit 2 = D.  off16 / id16: where the arrays start, in units of 16 words from the pool's base:
 // history = M offsets (w words, padded to 16) followed by one provenance byte per cell; I and D (w16 words each) in the ring chunk.
-struct Hdr { int lo, hi, lo_base, flags; uint32_t off16; int w; uint32_t id16; };
+struct Hdr { int lo, hi, lo_base, flags; uint32_t off16; int w; uint32_t id16; int res; };   // res: 1 + number of the step if its wavefronts went to LDS, else 0
 
 __device__ __forceinline__ int w16_of(int w) { return (w + 15) & ~15; }
 __device__ __forceinline__ bool in_range(const Hdr &h, int bit, int k) { return ((h.flags >> bit) & 1) && k >= h.lo && k <= h.hi; }
@@ -68,10 +70,13 @@ __device__ __forceinline__ int matching_prefix8(const uint8_t *a, const uint8_t 
   return d ? (int)(__builtin_ctzll(d) >> 3) : 8;
 }
 
+// barrier for steps whose wavefronts are exchanged through LDS only: the stores to the history in memory stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void pool_lock(PoolCtl *c) { while (atomicCAS(&c->lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4); __threadfence(); }
 __device__ __forceinline__ void pool_unlock(PoolCtl *c) { __threadfence(); atomicExch(&c->lock, 0); }
 
-__global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restrict__ ref, int plen, const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) void wfa_align_kernel(const uint8_t *__restrict__ ref, int plen, const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off,
                                                          const int *__restrict__ todo, int n_todo, uint8_t *__restrict__ aln, size_t aln_pitch, int *__restrict__ score_out,
                                                          int *__restrict__ status_out, unsigned long long *__restrict__ cells_out, uint32_t *__restrict__ pool,
                                                          PoolCtl *ctl, int *stack, int *next_query, WfaParams P)
@@ -82,6 +87,10 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
   __shared__ int wsync[2][NW][2];
   __shared__ int dend[2][2][64];           // distance to the end cell of a wavefront's first and last 64 diagonals (for the reduction)
   __shared__ int bc[2];
+  // The wavefronts a step reads -- M of score - x and score - o - e, I and D of score - e -- are those of the last few steps: they stay
+  // in LDS (offset + 16 in 16 bits: the null offset is 6) as long as they are at most WL wide, and the history in memory is written
+  // without being waited for.  A step then costs LDS latency plus one round trip for the characters of the extension.
+  __shared__ uint16_t lm[RM][WL], li[RID][WL], ld[RID][WL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk_log2 = ctl->chunk_log2;
   const unsigned chunk_words = 1u << chunk_log2;
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         auto load = [&](int s, Hdr &h) {
           if (s < 0) { h.flags = 0; return; }
           const int *r = ring[s & (RING - 1)];
-          h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off16 = (uint32_t)r[4]; h.w = r[5]; h.id16 = (uint32_t)r[6];
+          h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off16 = (uint32_t)r[4]; h.w = r[5]; h.id16 = (uint32_t)r[6]; h.res = r[7];
         };
         load(score - P.x, hs); load(score - P.oe, hg); load(score - P.e, he);
         const bool n_sub = !(hs.flags & 1), n_gap = !(hg.flags & 1), n_i = !(he.flags & 2), n_d = !(he.flags & 4);
@@ -181,6 +190,14 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         const size_t id_at = ring_base + ring_pos;
         ring_pos += 2u * (unsigned)w16;
         cells += (unsigned)w;
+        // where the wavefronts of this step and of its sources live
+        const bool resident = w <= WL && tlen + step + 32 < 65535;          // offsets grow by at most one per step beyond tlen
+        const bool id_to_memory = !resident || P.e >= RID;                  // (more existing scores between s - e and s than LDS slots: keep a copy)
+        const int cslot = step % RM, cislot = step % RID;
+        const bool lds_s = hs.res && step - (hs.res - 1) < RM, lds_g = hg.res && step - (hg.res - 1) < RM, lds_e = he.res && step - (he.res - 1) < RID;
+        const int slot_s = hs.res ? (hs.res - 1) % RM : 0, slot_g = hg.res ? (hg.res - 1) % RM : 0, slot_e = he.res ? (he.res - 1) % RID : 0;
+        // a source that left LDS is read from memory, where its step wrote it without waiting: make those stores complete first
+        if (((hs.flags & 1) && hs.res && !lds_s) || ((hg.flags & 1) && hg.res && !lds_g) || ((he.flags & 6) && he.res && !lds_e)) __syncthreads();
         uint32_t *out_m = pool + m_at, *out_i = pool + id_at, *out_d = out_i + w16;
         uint8_t *out_c = reinterpret_cast<uint8_t *>(out_m + w16);
         const uint32_t *ms = pool + ((size_t)hs.off16 << 4) - hs.lo_base, *mg = pool + ((size_t)hg.off16 << 4) - hg.lo_base;
@@ -194,13 +211,16 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
           unsigned code = C_MISMATCH;
           if (score > 0) {
             const bool in_s = in_range(hs, 0, k), in_gm = in_range(hg, 0, k - 1), in_gp = in_range(hg, 0, k + 1), in_i = in_range(he, 1, k - 1), in_d = in_range(he, 2, k + 1);
-            const int r_s = in_s ? (int)ms[k] : WFA_NULL, r_gm = in_gm ? (int)mg[k - 1] : WFA_NULL, r_gp = in_gp ? (int)mg[k + 1] : WFA_NULL;
-            const int r_i = in_i ? (int)ie[k - 1] : WFA_NULL, r_d = in_d ? (int)de[k + 1] : WFA_NULL;
+            const int r_s  = in_s  ? (lds_s ? (int)lm[slot_s][k - hs.lo_base] - 16     : (int)ms[k])     : WFA_NULL;
+            const int r_gm = in_gm ? (lds_g ? (int)lm[slot_g][k - 1 - hg.lo_base] - 16 : (int)mg[k - 1]) : WFA_NULL;
+            const int r_gp = in_gp ? (lds_g ? (int)lm[slot_g][k + 1 - hg.lo_base] - 16 : (int)mg[k + 1]) : WFA_NULL;
+            const int r_i  = in_i  ? (lds_e ? (int)li[slot_e][k - 1 - he.lo_base] - 16 : (int)ie[k - 1]) : WFA_NULL;
+            const int r_d  = in_d  ? (lds_e ? (int)ld[slot_e][k + 1 - he.lo_base] - 16 : (int)de[k + 1]) : WFA_NULL;
             // the five predecessors as the backtrace sees them (a "+ 1" belongs to a fetched value only)
             const int v_sub = in_s ? r_s + 1 : WFA_NULL, v_io = in_gm ? r_gm + 1 : WFA_NULL, v_ie = in_i ? r_i + 1 : WFA_NULL, v_do = r_gp, v_de = r_d;
             m = v_sub;
-            if (has_i) { const int ins = max(r_gm, r_i) + 1; if (act) out_i[k - lo] = (uint32_t)ins; m = max(m, ins); }
-            if (has_d) { const int del = max(r_gp, r_d);     if (act) out_d[k - lo] = (uint32_t)del; m = max(m, del); }
+            if (has_i) { const int ins = max(r_gm, r_i) + 1; if (act) { if (resident) li[cislot][k - lo] = (uint16_t)(ins + 16); if (id_to_memory) out_i[k - lo] = (uint32_t)ins; } m = max(m, ins); }
+            if (has_d) { const int del = max(r_gp, r_d);     if (act) { if (resident) ld[cislot][k - lo] = (uint16_t)(del + 16); if (id_to_memory) out_d[k - lo] = (uint32_t)del; } m = max(m, del); }
             const int bt = max(v_sub, max(max(v_io, v_ie), max(v_do, v_de)));
             code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
             code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
@@ -240,6 +260,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
           if (k0 == lo) dend[step & 1][0][lane] = dk_;
           if (k0 + 64 > hi) dend[step & 1][1][lane] = dk_;
           if (act) {
+            if (resident) lm[cslot][k - lo] = (uint16_t)(m + 16);
             out_m[k - lo] = (uint32_t)m;
             out_c[k - lo] = (uint8_t)code;
             min_distance = min(min_distance, dk_);
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         for (int o = 32; o > 0; o >>= 1) min_distance = min(min_distance, __shfl_xor(min_distance, o));
         const bool wave_hit = __any(hit_end);
         if (lane == 0) { wsync[step & 1][wave][0] = min_distance; wsync[step & 1][wave][1] = wave_hit ? 1 : 0; }
-        __syncthreads();                                        // the one barrier of a step: offsets stored by other waves are read from here on
+        if (resident) lds_barrier(); else __syncthreads();      // the one barrier of a step: offsets stored by other waves are read from here on
         min_distance = wsync[step & 1][0][0]; reached = wsync[step & 1][0][1] != 0;
 #pragma unroll
         for (int u = 1; u < NW; u++) { min_distance = min(min_distance, wsync[step & 1][u][0]); reached = reached || wsync[step & 1][u][1] != 0; }
@@ -267,7 +288,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             if (b0) rlo = lo + __builtin_ctzll(b0);
             else for (int k0 = lo + 64; k0 < top_limit; k0 += 64) {
               const int k = k0 + lane;
-              const bool keep = k < top_limit && dist_to_end(plen, tlen, (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
+              const bool keep = k < top_limit && dist_to_end(plen, tlen, resident ? (int)lm[cslot][k - lo] - 16 : (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
               const unsigned long long b = __ballot(keep);
               if (b) { rlo = k0 + __builtin_ctzll(b); break; }
             }
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             if (b0) rhi = kh + 63 - __builtin_clzll(b0);
             else for (int k0 = kh - 1; k0 > bottom_limit; k0 -= 64) {
               const int k = k0 - lane;
-              const bool keep = k > bottom_limit && dist_to_end(plen, tlen, (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
+              const bool keep = k > bottom_limit && dist_to_end(plen, tlen, resident ? (int)lm[cslot][k - lo] - 16 : (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
               const unsigned long long b = __ballot(keep);
               if (b) { rhi = k0 - __builtin_ctzll(b); break; }
             }
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         }
         if (lane < HDR_INTS) {
           const int flags = 1 | (has_i ? 2 : 0) | (has_d ? 4 : 0);
-          const int val = lane == 0 ? rlo : lane == 1 ? rhi : lane == 2 ? lo : lane == 3 ? flags : lane == 4 ? (int)(uint32_t)(m_at >> 4) : lane == 5 ? w : lane == 6 ? (int)(uint32_t)(id_at >> 4) : 0;
+          const int val = lane == 0 ? rlo : lane == 1 ? rhi : lane == 2 ? lo : lane == 3 ? flags : lane == 4 ? (int)(uint32_t)(m_at >> 4) : lane == 5 ? w : lane == 6 ? (int)(uint32_t)(id_at >> 4) : (resident ? step : 0);
           ring_out[lane] = val;
           if (wave == 0) hdr_out[lane] = val;
         }

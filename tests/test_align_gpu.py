@@ -162,3 +162,27 @@ def test_uvaialign_cli_matches_oracle(tmp_path):
     subprocess.run(cmd + ["-o", str(tmp_path / "out")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     with lzma.open(tmp_path / "out.aln.xz", "rb") as fh:
         assert fh.read() == r.stdout
+
+
+def test_uvaialign_cli_against_the_committed_snapshot(tmp_path):
+    """bin/uvaialign on real sequences (the bundled alignment with its gaps removed) against tests/golden/uvaialign_oracle_snapshot.json,
+    without the oracle in the loop: scores through the library, rows through the command line"""
+    import hashlib
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_golden_align", os.path.join(ROOT, "tools", "make_golden_align.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    snap = json.load(open(os.path.join(F.GOLDEN, "uvaialign_oracle_snapshot.json")))
+    ref_name, ref, qs = mod.pick()
+    assert ref_name == snap["reference"] and [n for n, _ in qs] == [q["name"] for q in snap["queries"]]
+    with align.Aligner(ref) as al:
+        score, rows = al.align([s for _, s in qs])
+    assert list(score) == [q["score"] for q in snap["queries"]]
+    assert [hashlib.sha1(r.tobytes()).hexdigest() for r in rows] == [q["row_sha1"] for q in snap["queries"]]
+    _write_fasta(tmp_path / "ref.fa", [ref_name], [ref])
+    _write_fasta(tmp_path / "q.fa", [n for n, _ in qs], [s for _, s in qs], width=80)
+    r = subprocess.run([UVAIALIGN, "-r", str(tmp_path / "ref.fa"), str(tmp_path / "q.fa"), "--stdout", "-a", "1.0"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    got_names, got_rows = F.read_fasta_bytes(r.stdout)
+    assert got_names == [q["name"] for q in snap["queries"]]
+    assert [hashlib.sha1(x).hexdigest() for x in got_rows] == [q["row_sha1"] for q in snap["queries"]]

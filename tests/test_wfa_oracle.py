@@ -83,3 +83,22 @@ def test_query_filter_of_the_read_loop():
     assert not O.uvaialign_accepts(ok + ok[:1501], ref_len) and O.uvaialign_accepts(ok + ok[:1500], ref_len)
     assert not O.uvaialign_accepts(b"N" * 1600 + ok[:1400], ref_len) and O.uvaialign_accepts(b"N" * 1400 + ok[:1600], ref_len)
     assert not O.uvaialign_accepts(b"Y" * 1500 + ok[:1500], ref_len, 0.3)       # too few ACGT although nothing is N
+
+
+def test_oracle_reproduces_its_committed_snapshot():
+    """tests/golden/uvaialign_oracle_snapshot.json (tools/make_golden_align.py): bundled sequences with their gaps removed against the
+    cleanest one.  A regression pin of the oracle's own numbers, not reference output."""
+    import hashlib
+    import json
+    import os
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_align", os.path.join(sys_path, "make_golden_align.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    snap = json.load(open(os.path.join(F.GOLDEN, "uvaialign_oracle_snapshot.json")))
+    ref_name, ref, qs = mod.pick()
+    assert ref_name == snap["reference"] and len(ref) == snap["reference_length"] and len(qs) == len(snap["queries"])
+    for (name, s), want in list(zip(qs, snap["queries"]))[:8]:              # the first eight: the whole list runs on the GPU test
+        score, row, cells = O.uvaialign_query(ref, s)
+        assert (name, len(s), score, cells, hashlib.sha1(row).hexdigest()) == (want["name"], want["length"], want["score"], want["cells"], want["row_sha1"])

@@ -275,7 +275,10 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     if (c->acgt) hipLaunchKernelGGL((consensus_rt_kernel<true>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, tiles, ptile_first, n_tiles, c->W4, c->d_cp, rt);
     else         hipLaunchKernelGGL((consensus_rt_kernel<false>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, tiles, ptile_first, n_tiles, c->W4, c->d_cp, rt);
   };
-  const int qt2 = c->qt == 8 ? 8 : 16;                           // query tile of the packed-plane scans (their partial sums share LDS: no 32)
+  // Query tile of the packed-plane scans (their partial sums share LDS: no 32).  With eight queries counted per plane word the
+  // kernel's VALU time equals its HBM time; a set of one, two or four queries is not padded to eight: the counting shrinks with it
+  // and the scan stays bound by HBM.
+  const int qt2 = c->qt != 8 ? 16 : c->nq <= 1 ? 1 : c->nq <= 2 ? 2 : c->nq <= 4 ? 4 : 8;
   const int n_qtiles = (c->nq + qt2 - 1) / qt2;
   dim3 grid(scan_grid_size(n_qtiles, n_tiles)), block(256);      // the packed-plane scans: one block per (query tile, tile of references)
   ScanEvt ev_{};
@@ -312,7 +315,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     return 0;
   }
 #define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt)
-#define LAUNCH_QT(K, CN) switch (qt2) { case 8: LAUNCH(K, 8, CN); break; default: LAUNCH(K, 16, CN); }
+#define LAUNCH_QT(K, CN) switch (qt2) { case 1: LAUNCH(K, 1, CN); break; case 2: LAUNCH(K, 2, CN); break; case 4: LAUNCH(K, 4, CN); break; case 8: LAUNCH(K, 8, CN); break; default: LAUNCH(K, 16, CN); }
   if (c->acgt) { if (cons) { LAUNCH_QT(scan2_acgt_kernel, true) } else { LAUNCH_QT(scan2_acgt_kernel, false) } }
   else         { if (cons) { LAUNCH_QT(scan2_iupac_kernel, true) } else { LAUNCH_QT(scan2_iupac_kernel, false) } }
 #undef LAUNCH_QT

@@ -186,7 +186,7 @@ create_query_indices (query_t qu)
   unsigned char *flags = (unsigned char *) biomcmc_malloc ((size_t) (L > 0 ? L : 1));      /* bit 0: polymorphic, bit 1: some query missing */
   memset (shared, 'N', (size_t) (L > 0 ? L : 1));
   memset (flags, 0, (size_t) (L > 0 ? L : 1));
-  const int block = 2048;
+  const int block = 256;      /* 117 blocks at 29 903 columns: work for every thread of the host (2 048 left all but 15 idle) */
 #pragma omp parallel for schedule(dynamic)
   for (int b0 = lo; b0 < hi; b0 += block) {
     const int b1 = b0 + block < hi ? b0 + block : hi;

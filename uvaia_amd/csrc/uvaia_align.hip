@@ -58,6 +58,7 @@ struct PoolCtl { int lock, top, n_chunks, chunk_log2; };
 // history = M offsets (w words, padded to 16) followed by one provenance byte per cell; I and D (w16 words each) in the ring chunk.
 struct Hdr { int lo, hi, lo_base, flags; uint32_t off16; int w; uint32_t id16; int res; };   // res: 1 + number of the step if its wavefronts went to LDS, else 0
 
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int w16_of(int w) { return (w + 15) & ~15; }
 __device__ __forceinline__ bool in_range(const Hdr &h, int bit, int k) { return ((h.flags >> bit) & 1) && k >= h.lo && k <= h.hi; }
 __device__ __forceinline__ int dist_to_end(int plen, int tlen, int offset, int k) { return max(plen - (offset - k), tlen - offset); }
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       else {
         auto load = [&](int s, Hdr &h) {
           if (s < 0) { h.flags = 0; return; }
-          const int *r = ring[s & (RING - 1)];
-          h.lo = r[0]; h.hi = r[1]; h.lo_base = r[2]; h.flags = r[3]; h.off16 = (uint32_t)r[4]; h.w = r[5]; h.id16 = (uint32_t)r[6]; h.res = r[7];
+          const int *r = ring[s & (RING - 1)];            // the same for every lane: kept in scalar registers
+          h.lo = rfl(r[0]); h.hi = rfl(r[1]); h.lo_base = rfl(r[2]); h.flags = rfl(r[3]); h.off16 = (uint32_t)rfl(r[4]); h.w = rfl(r[5]); h.id16 = (uint32_t)rfl(r[6]); h.res = rfl(r[7]);
         };
         load(score - P.x, hs); load(score - P.oe, hg); load(score - P.e, he);
         const bool n_sub = !(hs.flags & 1), n_gap = !(hg.flags & 1), n_i = !(he.flags & 2), n_d = !(he.flags & 4);
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int cslot = step % RM, cislot = step % RID;
         const bool lds_s = hs.res && step - (hs.res - 1) < RM, lds_g = hg.res && step - (hg.res - 1) < RM, lds_e = he.res && step - (he.res - 1) < RID;
         const int slot_s = hs.res ? (hs.res - 1) % RM : 0, slot_g = hg.res ? (hg.res - 1) % RM : 0, slot_e = he.res ? (he.res - 1) % RID : 0;
+        const bool all_lds = (!(hs.flags & 1) || lds_s) && (!(hg.flags & 1) || lds_g) && (!(he.flags & 6) || lds_e);
         // a source that left LDS is read from memory, where its step wrote it without waiting: make those stores complete first
         if (((hs.flags & 1) && hs.res && !lds_s) || ((hg.flags & 1) && hg.res && !lds_g) || ((he.flags & 6) && he.res && !lds_e)) __syncthreads();
         uint32_t *out_m = pool + m_at, *out_i = pool + id_at, *out_d = out_i + w16;
@@ -211,11 +213,19 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
           unsigned code = C_MISMATCH;
           if (score > 0) {
             const bool in_s = in_range(hs, 0, k), in_gm = in_range(hg, 0, k - 1), in_gp = in_range(hg, 0, k + 1), in_i = in_range(he, 1, k - 1), in_d = in_range(he, 2, k + 1);
-            const int r_s  = in_s  ? (lds_s ? (int)lm[slot_s][k - hs.lo_base] - 16     : (int)ms[k])     : WFA_NULL;
-            const int r_gm = in_gm ? (lds_g ? (int)lm[slot_g][k - 1 - hg.lo_base] - 16 : (int)mg[k - 1]) : WFA_NULL;
-            const int r_gp = in_gp ? (lds_g ? (int)lm[slot_g][k + 1 - hg.lo_base] - 16 : (int)mg[k + 1]) : WFA_NULL;
-            const int r_i  = in_i  ? (lds_e ? (int)li[slot_e][k - 1 - he.lo_base] - 16 : (int)ie[k - 1]) : WFA_NULL;
-            const int r_d  = in_d  ? (lds_e ? (int)ld[slot_e][k + 1 - he.lo_base] - 16 : (int)de[k + 1]) : WFA_NULL;
+            int r_s, r_gm, r_gp, r_i, r_d;
+            if (all_lds) {     // the usual case: five unconditional LDS reads at clamped positions, the range tests as selects (no branches)
+              const int xs = min(max(k - hs.lo_base, 0), WL - 1), xm = min(max(k - 1 - hg.lo_base, 0), WL - 1), xp = min(max(k + 1 - hg.lo_base, 0), WL - 1);
+              const int xi = min(max(k - 1 - he.lo_base, 0), WL - 1), xd = min(max(k + 1 - he.lo_base, 0), WL - 1);
+              const int a_s = (int)lm[slot_s][xs] - 16, a_m = (int)lm[slot_g][xm] - 16, a_p = (int)lm[slot_g][xp] - 16, a_i = (int)li[slot_e][xi] - 16, a_d = (int)ld[slot_e][xd] - 16;
+              r_s = in_s ? a_s : WFA_NULL; r_gm = in_gm ? a_m : WFA_NULL; r_gp = in_gp ? a_p : WFA_NULL; r_i = in_i ? a_i : WFA_NULL; r_d = in_d ? a_d : WFA_NULL;
+            } else {
+              r_s  = in_s  ? (lds_s ? (int)lm[slot_s][k - hs.lo_base] - 16     : (int)ms[k])     : WFA_NULL;
+              r_gm = in_gm ? (lds_g ? (int)lm[slot_g][k - 1 - hg.lo_base] - 16 : (int)mg[k - 1]) : WFA_NULL;
+              r_gp = in_gp ? (lds_g ? (int)lm[slot_g][k + 1 - hg.lo_base] - 16 : (int)mg[k + 1]) : WFA_NULL;
+              r_i  = in_i  ? (lds_e ? (int)li[slot_e][k - 1 - he.lo_base] - 16 : (int)ie[k - 1]) : WFA_NULL;
+              r_d  = in_d  ? (lds_e ? (int)ld[slot_e][k + 1 - he.lo_base] - 16 : (int)de[k + 1]) : WFA_NULL;
+            }
             // the five predecessors as the backtrace sees them (a "+ 1" belongs to a fetched value only)
             const int v_sub = in_s ? r_s + 1 : WFA_NULL, v_io = in_gm ? r_gm + 1 : WFA_NULL, v_ie = in_i ? r_i + 1 : WFA_NULL, v_do = r_gp, v_de = r_d;
             m = v_sub;

@@ -207,7 +207,7 @@ namespace {
 template <class F>
 static void parallel_for(int n, F f)
 {
-  const unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  const unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);   // (16 until round 2: 0.33 s of a 10 000-query open were these loops)
   if (n < 32 || nt < 2) { for (int i = 0; i < n; i++) f(i); return; }
   std::atomic<int> next(0);
   std::vector<std::thread> th;

@@ -289,7 +289,7 @@ def align_workload(hostlib, n_query, steps, nchar, seed, preset, device, n_cpu, 
            "cells_per_query": round(st["cells"] / n_query), "median_score": int(np.median(score)), "max_score": int(score.max()),
            "cell_updates_per_s": round(st["cells"] * steps / elapsed), "wavefront_bytes_per_cell": 33,
            "wavefront_GBps": round(st["wavefront_bytes"] * steps / elapsed / 1e9, 1), "frac_of_hbm_peak": round(st["wavefront_bytes"] * steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-           "note": "a query is a chain of one dependent step per score (thousands; N runs cost 4 per site), 1 000-2 500 diagonals wide for most of them: one block of eight waves "
+           "note": "a query is a chain of one dependent step per score (thousands; N runs cost 4 per site), 1 000-2 500 diagonals wide for most of them: one block of four waves "
                    "per query, the wavefronts of the last steps in LDS, a step = five earlier offsets per cell + extension + one LDS barrier; per cell 5 bytes go to memory for the "
                    "backtrace (M offset + provenance byte), 8 are I/D offsets, 20 are read (wavefront_GBps counts these 33 algorithmic bytes; with LDS residency only the 5 reach HBM).  Rows and scores equal the CPU restatement's (oracle/wfa_oracle.c; parity unpinned beyond "
                    "the optimal gap-affine score)"}

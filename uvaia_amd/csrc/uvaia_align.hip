@@ -34,7 +34,7 @@
 namespace {
 
 constexpr int WFA_NULL = -10;            // offset of a diagonal a wavefront does not hold (oracle/wfa_oracle.c)
-constexpr int NW = 8;                    // waves per block = per query
+constexpr int NW = 4;                    // waves per block = per query
 constexpr int TPB = 64 * NW;
 constexpr int RING = 64;                 // scores whose headers stay in LDS; penalties are below this
 constexpr int HDR_INTS = 8;
@@ -46,7 +46,7 @@ constexpr int RM = 5, RID = 2;           // LDS slots: M wavefronts of the last 
 enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3, ST_TOOWIDE = 4 };
 enum { C_DEL_EXT = 0, C_DEL_OPEN = 1, C_INS_EXT = 2, C_INS_OPEN = 3, C_MISMATCH = 4, C_I_EXT = 8, C_D_EXT = 16 };
 
-struct WfaParams { int x, oe, e, min_wf_len, max_dist_thr, max_score; };
+struct WfaParams { int x, oe, e, min_wf_len, max_dist_thr, max_score, g; };
 
 // Workspace: chunks of 2^chunk_log2 words handed out from a stack under a spin lock (one thread of a block at a time, the others
 // wait at a barrier; a query takes a chunk every few hundred thousand cells).  Block b owns chunks 2b (first history chunk) and
@@ -77,7 +77,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void pool_lock(PoolCtl *c) { while (atomicCAS(&c->lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4); __threadfence(); }
 __device__ __forceinline__ void pool_unlock(PoolCtl *c) { __threadfence(); atomicExch(&c->lock, 0); }
 
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) void wfa_align_kernel(const uint8_t *__restrict__ ref, int plen, const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off,
+__global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restrict__ ref, int plen, const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off,
                                                          const int *__restrict__ todo, int n_todo, uint8_t *__restrict__ aln, size_t aln_pitch, int *__restrict__ score_out,
                                                          int *__restrict__ status_out, unsigned long long *__restrict__ cells_out, uint32_t *__restrict__ pool,
                                                          PoolCtl *ctl, int *stack, int *next_query, WfaParams P)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 
     // ---------------- forward: one step per score ----------------
     for (;;) {
-      if ((score & (HDR_PAGE_SCORES - 1)) == 0) {               // a new page of headers
+      if (score / HDR_PAGE_SCORES != (score - P.g) / HDR_PAGE_SCORES || score == 0) {     // a new page of headers
         const int page = score / HDR_PAGE_SCORES;
         size_t at = 0;
         if (page >= MAX_HDR_PAGES) { status = ST_MAXSCORE; break; }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
       }
       if (reached) break;
-      score++;
+      score += P.g;                                             // scores that are no multiple of gcd(x, o + e, e) have no wavefront (and no header: never looked up)
       if (score > P.max_score) { status = ST_MAXSCORE; break; }
     }
     __syncthreads();                                            // headers in memory, last offsets: visible to the backtrace
@@ -563,6 +563,7 @@ int uvaia_align_open(uvaia_aligner **out, const char *ref, int ref_len, int devi
   a->device = device; a->plen = ref_len;
   a->P.x = opt.mismatch; a->P.oe = opt.gap_opening + opt.gap_extension; a->P.e = opt.gap_extension;
   a->P.min_wf_len = opt.min_wavefront_length; a->P.max_dist_thr = opt.max_distance_threshold;
+  { int g = a->P.x, b = a->P.oe; while (b) { const int t = g % b; g = b; b = t; } b = a->P.e; while (b) { const int t = g % b; g = b; b = t; } a->P.g = g; }
   // table size of affine_wavefronts_new_reduced (L, 3 L, ..): min(L, 3L) * mismatch + gap_opening + |L - 3L| * gap_extension
   const long long ms = (long long)ref_len * opt.mismatch + opt.gap_opening + 2LL * ref_len * opt.gap_extension;
   a->P.max_score = (int)std::min<long long>(ms, 0x3fffffff);

@@ -78,7 +78,8 @@ typedef struct {
   int serial;                  /* 1 = no overlap between the rebuild of the derived planes, the scans and the replays (isolated kernel timings) */
   int scan_tiles_per_wave;     /* column-compressed scan: 1 or 2 tiles of 64 references per wave (default 2) */
   int scan_waves_per_block;    /* column-compressed scan: 4 or 8 waves share a super-tile of 64 queries (default 8) */
-  int reserved[8];             /* zero */
+  int rederive_streams;        /* uvaia_gpu_db_rederive: its chunks alternate over 1..3 streams (default 3: all chunks in flight at once, the first still done first) */
+  int reserved[7];             /* zero */
 } uvaia_gpu_tuning;
 int uvaia_gpu_open_tuned (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning /* may be NULL */);
 void uvaia_gpu_close (uvaia_gpu_ctx *ctx);

@@ -75,6 +75,8 @@ struct uvaia_gpu_ctx {
   // uvaia_gpu_db_rederive: chunks of tiles rebuilt on their own stream; a scan waits for the chunks its slice touches
   struct DeriveChunk { long long t0, t1; hipEvent_t done; };
   hipStream_t derive_stream = nullptr;
+  hipStream_t derive_streams[3] = {};     // [0] = derive_stream; the chunks of a rebuild alternate over the first derive_nstreams
+  int derive_nstreams = 3;
   std::vector<DeriveChunk> derive_chunks;
   hipEvent_t derive_fence[4] = {};
   size_t derive_pending = 0;          // chunks of the last rederive a scan may still have to wait for
@@ -418,7 +420,7 @@ int derive_rows(uvaia_gpu_ctx *c, uint4 *tiles, long long slot0, int n_ref, hipS
 // a rebuild of the derived planes still in flight (uvaia_gpu_db_rederive) must end before the database changes
 static int settle_derive(uvaia_gpu_ctx *c)
 {
-  if (c->derive_pending) { HIPCHK(c, hipStreamSynchronize(c->derive_stream)); c->derive_pending = 0; }
+  if (c->derive_pending) { for (int i_ = 0; i_ < 3; i_++) if (c->derive_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->derive_streams[i_])); c->derive_pending = 0; }
   return 0;
 }
 
@@ -481,7 +483,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   for (int i = 0; i < 2; i++) if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
   for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); if (c->d_rtb[i]) hipFree(c->d_rtb[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
-  if (c->derive_stream) { hipStreamSynchronize(c->derive_stream); hipStreamDestroy(c->derive_stream); }
+  for (int i_ = 0; i_ < 3; i_++) if (c->derive_streams[i_]) { hipStreamSynchronize(c->derive_streams[i_]); hipStreamDestroy(c->derive_streams[i_]); }
   for (auto &d : c->derive_chunks) hipEventDestroy(d.done);
   for (int i = 0; i < 4; i++) if (c->derive_fence[i]) hipEventDestroy(c->derive_fence[i]);
   if (c->scan_stream) hipStreamDestroy(c->scan_stream);
@@ -527,6 +529,7 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   if (tn.scan_tiles_per_wave) c->scan_R = tn.scan_tiles_per_wave;
   if (tn.scan_waves_per_block) c->scan_NW = tn.scan_waves_per_block;
   if (tn.subslice_refs) { c->subslice = tn.subslice_refs; c->subslice_forced = true; }
+  if (tn.rederive_streams >= 1 && tn.rederive_streams <= 3) c->derive_nstreams = tn.rederive_streams;
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
   // four-counter scan instead (32-bit counts, same results, slower)
   if (c->nchar > 49000) c->fullscan = true;
@@ -545,7 +548,8 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     for (int i = 1; i < 3; i++) OPENCHK(hipStreamCreateWithPriority(&c->scan_streams[i], hipStreamNonBlocking, prio_least));
     for (int i = 0; i < NBUF; i++) { OPENCHK(hipEventCreateWithFlags(&c->scan_done[i], hipEventDisableTiming)); OPENCHK(hipEventCreateWithFlags(&c->replay_done[i], hipEventDisableTiming)); }
     // between the scan (lowest) and the replay (highest): its blocks take the slots scan blocks free, ahead of the next scan blocks
-    OPENCHK(hipStreamCreateWithPriority(&c->derive_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
+    for (int i = 0; i < 3; i++) OPENCHK(hipStreamCreateWithPriority(&c->derive_streams[i], hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
+    c->derive_stream = c->derive_streams[0];
   }
   uint8_t code_tab[256]; fill_code_table(code_tab);
   OPENCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_code), code_tab, 256));
@@ -1163,7 +1167,7 @@ int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
       if (!busy[i]) continue;
       if (!c->derive_fence[i]) HIPCHK(c, hipEventCreateWithFlags(&c->derive_fence[i], hipEventDisableTiming));
       HIPCHK(c, hipEventRecord(c->derive_fence[i], busy[i]));
-      HIPCHK(c, hipStreamWaitEvent(c->derive_stream, c->derive_fence[i], 0));
+      for (int j = 0; j < c->derive_nstreams; j++) HIPCHK(c, hipStreamWaitEvent(c->derive_streams[j], c->derive_fence[i], 0));
     }
   }
   std::vector<SubSlice> plan = plan_subslices(c, 0, c->db_n, c->max_pool);
@@ -1178,9 +1182,10 @@ int uvaia_gpu_db_rederive(uvaia_gpu_ctx *c)
       HIPCHK(c, hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
       c->derive_chunks.push_back(d);
     }
-    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), c->derive_stream, true); if (rc) return rc;
+    hipStream_t ds = c->derive_streams[k % (size_t)c->derive_nstreams];
+    int rc = derive_rows(c, c->d_db, t0 * 64, (int)((t1 - t0) * 64), ds, true); if (rc) return rc;
     c->derive_chunks[k].t0 = t0; c->derive_chunks[k].t1 = t1;
-    HIPCHK(c, hipEventRecord(c->derive_chunks[k].done, c->derive_stream));
+    HIPCHK(c, hipEventRecord(c->derive_chunks[k].done, ds));
     k++;
   }
   c->derive_pending = k;
@@ -1254,7 +1259,7 @@ int uvaia_gpu_search_resident_pool(uvaia_gpu_ctx *c, size_t first, size_t n, int
 int uvaia_gpu_sync(uvaia_gpu_ctx *c)
 {
   if (!c) return UVAIA_GPU_EINVAL;
-  if (c->derive_stream) HIPCHK(c, hipStreamSynchronize(c->derive_stream));
+  for (int i_ = 0; i_ < 3; i_++) if (c->derive_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->derive_streams[i_]));
   c->derive_pending = 0;
   for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -166,6 +166,13 @@ unsigned long long uvaia_gpu_ball_asked (uvaia_gpu_ctx *ctx, int reset);    /* r
  * sequences themselves gives the whole pair matrix; the host then walks it in the reference's order. */
 int uvaia_gpu_agree_on_polymorphic (uvaia_gpu_ctx *ctx, const char *const *seq, int n_seq, uint8_t *out);
 
+/* create_query_indices (src/fastaseq.c:732-777) on the device; no context needed (device < 0: the current one).  seq: n_query rows of
+ * nchar bytes as the reference holds them at that point (upper-case).  Out, per column: consensus[i] as the reference defines it
+ * ('N' outside the trimmed window or where no query is usable -- valid, with acgt != 0 ACGT --, '#' where two usable characters
+ * differ, else the shared character) and some_missing[i] = 1 where some query is not usable (the reference's miss[], :744-756).
+ * The caller builds idx / idx_m / idx_c from them exactly as src/fastaseq.c:763-770 does. */
+int uvaia_gpu_query_columns (const char *const *seq, int n_query, int nchar, size_t trim, int acgt, int device, char *consensus, unsigned char *some_missing);
+
 /* ---- introspection used by tests and bench.py ---- */
 /* untruncated pair scores of the last batch: out[(i*n_query+q)*6 + s] = the score[] vector src/nearest.c:499-501
  * (or :464-469 with --acgt) assembles for (reference i of the batch, query q) when nothing is truncated. */

@@ -79,3 +79,33 @@ def test_large_query_sets_prune_on_the_device_by_default():
     dev = H.PreparedQuery(qs, names, keep_resolved=True)
     gold = O.Query(qs, names, keep_resolved=True)
     assert dev.names == gold.names and dev.ntax < len(qs)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("trim", [0, 150])
+def test_column_classes_on_the_device_equal_oracle(acgt, trim):
+    """uvaia_gpu_query_columns = the walk of create_query_indices (src/fastaseq.c:732-777): consensus characters and the three index
+    classes; several batches of rows (the batch is capped by the staging buffer) and a last partial group of 64"""
+    qs, _, _ = F.synth_alignment(333, 2300, seed=31, p_amb=0.003)
+    q = O.Query(qs, ["q%d" % i for i in range(len(qs))], acgt=acgt, trim=trim)
+    cons, miss = capi.query_columns(q.seqs, trim=q.trim, acgt=acgt)
+    assert cons == q.consensus
+    cols = np.arange(q.nchar)
+    inside = (cols >= q.trim) & (cols < q.nchar - q.trim)
+    c = np.frombuffer(cons, dtype=np.uint8)
+    assert np.array_equal(cols[inside & (c == ord("#"))], q.idx)
+    assert np.array_equal(cols[inside & (c != ord("#")) & (c != ord("N")) & (miss == 1)], q.idx_m)
+    assert np.array_equal(cols[inside & (c != ord("#")) & (c != ord("N")) & (miss == 0)], q.idx_c)
+
+
+def test_many_queries_take_the_device_walk_by_default():
+    """from 2 048 queries on create_query_indices runs its column walk on the device without any switch (30 kb rows: several staging
+    batches); same query structure as the oracle's"""
+    gen = H.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, 2500)
+    names = ["q%d" % i for i in range(len(qs))]
+    dev = H.PreparedQuery(qs, names)
+    gold = O.Query(qs, names)
+    assert dev.names == gold.names and dev.consensus == gold.consensus
+    for f in ("idx_c", "idx_m", "idx"):
+        assert np.array_equal(getattr(dev, f), getattr(gold, f)), f

@@ -14,7 +14,7 @@ NSCORE = 6
 SYMBOLS = [
     "uvaia_gpu_open", "uvaia_gpu_open_tuned", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
-    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_agree_on_polymorphic",
+    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_agree_on_polymorphic", "uvaia_gpu_query_columns",
     "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
@@ -110,6 +110,7 @@ def load_library():
         "uvaia_gpu_ball_resident": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int, pi]),
         "uvaia_gpu_ball_asked": (C.c_ulonglong, [vp, C.c_int]),
         "uvaia_gpu_agree_on_polymorphic": (C.c_int, [vp, pp, C.c_int, C.POINTER(C.c_uint8)]),
+        "uvaia_gpu_query_columns": (C.c_int, [pp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_uint8)]),
         "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
         "uvaia_gpu_scan_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]),
         "uvaia_gpu_replay_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.c_int]),
@@ -534,3 +535,16 @@ class Group:
         pi = C.POINTER(C.c_int)
         self._chk(self.L.uvaia_gpu_group_drain(self.g, n.ctypes.data_as(pi), T.ctypes.data_as(pi), sc.ctypes.data_as(pi), od.ctypes.data_as(C.POINTER(C.c_int64))))
         return n, T, sc, od
+
+
+def query_columns(seqs, trim=0, acgt=False, device=-1):
+    """create_query_indices' column walk on the device (uvaia_gpu_query_columns): (consensus bytes, some_missing uint8 array)."""
+    L = load_library()
+    n, nchar = len(seqs), len(seqs[0])
+    arr = (C.c_char_p * n)(*seqs)
+    cons = C.create_string_buffer(nchar)
+    miss = np.zeros(nchar, dtype=np.uint8)
+    rc = L.uvaia_gpu_query_columns(arr, n, nchar, int(trim), int(bool(acgt)), int(device), cons, miss.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc:
+        raise GpuError(rc, (L.uvaia_gpu_last_error(None) or b"").decode())
+    return cons.raw[:nchar], miss

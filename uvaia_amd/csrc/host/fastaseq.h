@@ -43,6 +43,8 @@ query_t new_query_structure_from_fasta (char *filename, int trim, int dist, int 
 query_t new_query_structure_from_alignment (alignment aln, int trim, int dist, int acgt);   /* takes ownership of aln */
 void del_query_structure (query_t qu);
 void create_query_indices (query_t qu);
+/* same result from a column walk done elsewhere (the device: uvaia_gpu_query_columns); not in the reference's header */
+void create_query_indices_given (query_t qu, const char *consensus, const unsigned char *some_missing);
 void reorder_query_structure (query_t qu);
 void exclude_redundant_query_sequences (query_t qu, int keep_more_resolved);
 /* same walk with the O(Q^2) pair test handed in (NULL: computed here); not in the reference's header */

@@ -27,8 +27,10 @@ exclude_redundant_query_sequences_device (query_t query, int keep_resolved)
 }
 
 /* the pair test costs O(Q^2 x polymorphic columns) on one host thread (14 s at 3 000 queries): from this many queries on it
-   runs on the device.  uvaia_set_prune_mode() overrides (tests). */
+   runs on the device; the O(Q x L) column walk of create_query_indices from 2 048 queries on (below that the upload of the rows
+   costs what the host threads need for the walk).  uvaia_set_prune_mode() overrides both (tests). */
 #define UVAIA_PRUNE_DEVICE_FROM 512
+#define UVAIA_COLUMNS_DEVICE_FROM 2048
 static int prune_mode = 0;     /* 0 = by query count, 1 = host, 2 = device */
 void uvaia_set_prune_mode (int mode) { prune_mode = (mode == 1 || mode == 2) ? mode : 0; }
 static int
@@ -36,6 +38,21 @@ prune_on_device (int ntax)
 {
   if (prune_mode) return prune_mode == 2;
   return ntax >= UVAIA_PRUNE_DEVICE_FROM;
+}
+
+/* create_query_indices (src/fastaseq.c:732-777) with its walk over all query characters on the device */
+static void
+create_query_indices_where_it_pays (query_t query)
+{
+  const int n = query->aln->ntax, L = query->aln->nchar;
+  const int device = prune_mode ? prune_mode == 2 : n >= UVAIA_COLUMNS_DEVICE_FROM;
+  if (!device || L < 1) { create_query_indices (query); return; }
+  char *consensus = (char *) biomcmc_malloc ((size_t) L);
+  unsigned char *missing = (unsigned char *) biomcmc_malloc ((size_t) L);
+  if (uvaia_gpu_query_columns ((const char *const *) query->aln->character->string, n, L, query->trim, query->acgt, -1, consensus, missing))
+    biomcmc_error ("column classes of the queries on the GPU: %s (uvaia_set_prune_mode(1) runs the host loop instead)", uvaia_gpu_last_error (NULL));
+  create_query_indices_given (query, consensus, missing);
+  free (consensus); free (missing);
 }
 
 query_t
@@ -46,12 +63,12 @@ uvaia_prepare_query (alignment aln, int trim, int dist, int acgt, double ambig_q
   query_t query = new_query_structure_from_alignment (aln, trim, dist, acgt);
   uvaia_keep_only_valid_sequences (query->aln, ambig_q, true);
   if (query->aln->ntax < 1) return query;
-  create_query_indices (query);
+  create_query_indices_where_it_pays (query);
   reorder_query_structure (query);
   if (is_ball || keep_resolved) {
     if (prune_on_device (query->aln->ntax)) exclude_redundant_query_sequences_device (query, keep_resolved);
     else exclude_redundant_query_sequences (query, keep_resolved);
-    create_query_indices (query);
+    create_query_indices_where_it_pays (query);
   }
   return query;
 }

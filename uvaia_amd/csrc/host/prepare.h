@@ -11,7 +11,8 @@ extern "C" {
 query_t uvaia_prepare_query (alignment aln, int trim, int dist, int acgt, double ambig_q, int keep_resolved, int is_ball);
 query_t uvaia_prepare_query_from_arrays (int ntax, int nchar, const char *const *seqs, const char *const *names,
                                          int trim, int dist, int acgt, double ambig_q, int keep_resolved, int is_ball);
-/* where the O(Q^2) pair test of exclude_redundant_query_sequences runs: 0 = device from 512 queries on (default), 1 = host, 2 = device */
+/* where the query preprocessing runs -- the O(Q^2) pair test of exclude_redundant_query_sequences and the O(Q x L) column walk of
+ * create_query_indices: 0 = on the device from 512 / 2 048 queries on (default), 1 = host, 2 = device */
 void uvaia_set_prune_mode (int mode);
 
 #ifdef __cplusplus

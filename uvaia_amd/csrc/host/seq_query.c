@@ -166,19 +166,42 @@ char_is_acgt (unsigned char c)
 static inline int
 usable (const query_t qu, char c) { return qu->acgt ? char_is_acgt ((unsigned char) c) : char_is_valid ((unsigned char) c); }
 
+/* idx / idx_m / idx_c from the per-column result of the walk over the queries (src/fastaseq.c:758-776): consensus[] as the
+   reference defines it, some_missing[] its miss[] flags */
+static void
+indices_from_columns (query_t qu, const unsigned char *some_missing)
+{
+  const int L = qu->aln->nchar, lo = (int) qu->trim, hi = L - (int) qu->trim;
+  size_t span = hi > lo ? (size_t) (hi - lo) : 0;
+  qu->idx_c = (size_t *) biomcmc_realloc (qu->idx_c, (span + 1) * sizeof (size_t));
+  qu->idx_m = (size_t *) biomcmc_realloc (qu->idx_m, (span + 1) * sizeof (size_t));
+  qu->idx   = (size_t *) biomcmc_realloc (qu->idx,   (span + 1) * sizeof (size_t));
+  qu->n_idx_c = qu->n_idx_m = qu->n_idx = 0;
+  for (int col = lo; col < hi; col++) {
+    if (qu->consensus[col] == '#') qu->idx[qu->n_idx++] = (size_t) col;
+    else if (qu->consensus[col] != 'N') { if (some_missing[col]) qu->idx_m[qu->n_idx_m++] = (size_t) col; else qu->idx_c[qu->n_idx_c++] = (size_t) col; }
+  }
+  fprintf (stderr, "Query sequence alignment: %d segregating, %d non-segregating sites with indels, and %d constant sites (all are used in comparisons)\n",
+           qu->n_idx, qu->n_idx_m, qu->n_idx_c);
+}
+
+void
+create_query_indices_given (query_t qu, const char *consensus, const unsigned char *some_missing)
+{ /* the column walk was done elsewhere (uvaia_gpu_query_columns): take its result */
+  const int L = qu->aln->nchar;
+  if (!qu->consensus) qu->consensus = (char *) biomcmc_malloc ((size_t) (L > 0 ? L : 1));
+  memcpy (qu->consensus, consensus, (size_t) L);
+  indices_from_columns (qu, some_missing);
+}
+
 void
 create_query_indices (query_t qu)
 { /* classify every column inside the trimmed window from what the usable query characters show there */
   const int L = qu->aln->nchar, lo = (int) qu->trim, hi = L - (int) qu->trim, n = qu->aln->ntax;
   char **s = qu->aln->character->string;
   initialise_acgt ();
-  if (!qu->consensus) qu->consensus = (char *) biomcmc_malloc ((size_t) L);
+  if (!qu->consensus) qu->consensus = (char *) biomcmc_malloc ((size_t) (L > 0 ? L : 1));
   memset (qu->consensus, 'N', (size_t) L);
-  size_t span = hi > lo ? (size_t) (hi - lo) : 0;
-  qu->idx_c = (size_t *) biomcmc_realloc (qu->idx_c, (span + 1) * sizeof (size_t));
-  qu->idx_m = (size_t *) biomcmc_realloc (qu->idx_m, (span + 1) * sizeof (size_t));
-  qu->idx   = (size_t *) biomcmc_realloc (qu->idx,   (span + 1) * sizeof (size_t));
-  qu->n_idx_c = qu->n_idx_m = qu->n_idx = 0;
   /* Per column: the first usable character, whether a later usable one differs (polymorphic) and whether some query is not
      usable there.  Walked query by query (rows are contiguous) in blocks of columns, one block per thread: same classes as a
      column-by-column walk over the queries, without its strided reads. */
@@ -201,15 +224,12 @@ create_query_indices (query_t qu)
     }
   }
   for (int col = lo; col < hi; col++) {
-    if (flags[col] & 1) { qu->consensus[col] = '#'; qu->idx[qu->n_idx++] = (size_t) col; }
-    else if (shared[col] != 'N') {
-      qu->consensus[col] = shared[col];
-      if (flags[col] & 2) qu->idx_m[qu->n_idx_m++] = (size_t) col; else qu->idx_c[qu->n_idx_c++] = (size_t) col;
-    }
+    qu->consensus[col] = (flags[col] & 1) ? '#' : shared[col];
+    flags[col] = (unsigned char) ((flags[col] & 2) ? 1 : 0);
   }
-  free (shared); free (flags);
-  fprintf (stderr, "Query sequence alignment: %d segregating, %d non-segregating sites with indels, and %d constant sites (all are used in comparisons)\n",
-           qu->n_idx, qu->n_idx_m, qu->n_idx_c);
+  free (shared);
+  indices_from_columns (qu, flags);
+  free (flags);
 }
 
 typedef struct { int key, pos; } keyed_pos;

@@ -938,6 +938,63 @@ int uvaia_gpu_agree_on_polymorphic(uvaia_gpu_ctx *c, const char *const *seq, int
   return 0;
 }
 
+// create_query_indices (src/fastaseq.c:732-777) needs no context: the query rows go to the device in batches through a pinned
+// staging buffer (host copies threaded), two small kernels per batch, the per-column result comes back as two byte arrays.
+int uvaia_gpu_query_columns(const char *const *seq, int n_query, int nchar, size_t trim, int acgt, int device, char *consensus, unsigned char *some_missing)
+{
+  if (!seq || !consensus || !some_missing || n_query < 1 || nchar < 1) return fail(nullptr, UVAIA_GPU_EINVAL, "empty query set");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, UVAIA_GPU_ENODEV, "no HIP device available: the MI355X engine has no CPU fallback");
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= ndev || hipSetDevice(device) != hipSuccess) return fail(nullptr, UVAIA_GPU_ENODEV, "device %d is not usable", device);
+  const int lo = (int)std::min<size_t>(trim, (size_t)nchar), hi = std::max(lo, nchar - (int)std::min<size_t>(trim, (size_t)nchar));
+  memset(consensus, 'N', (size_t)nchar);
+  memset(some_missing, 0, (size_t)nchar);
+  if (hi <= lo) return 0;
+  const size_t pitch = ((size_t)nchar + 63) / 64 * 64;
+  const int batch = (int)std::max<size_t>(64, std::min<size_t>(4096, ((size_t)96 << 20) / pitch) / 64 * 64);      // rows per batch: at most 96 MB of staging
+  const int groups = batch / 64;
+  uint8_t *h_rows = nullptr, *d_rows = nullptr, *d_pf = nullptr, *d_pl = nullptr, *d_first = nullptr, *d_flags = nullptr;
+  hipStream_t st = nullptr;
+  hipError_t e = hipSuccess;
+  auto done = [&](int rc) { if (st) hipStreamDestroy(st); hipFree(d_rows); hipFree(d_pf); hipFree(d_pl); hipFree(d_first); hipFree(d_flags); if (h_rows) hipHostFree(h_rows); return rc; };
+#define QCHK(call) do { e = (call); if (e != hipSuccess) return done(fail(nullptr, e == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s", #call, hipGetErrorString(e))); } while (0)
+  QCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  QCHK(hipHostMalloc(&h_rows, (size_t)2 * batch * pitch, hipHostMallocDefault));
+  QCHK(hipMalloc(&d_rows, (size_t)2 * batch * pitch));
+  QCHK(hipMalloc(&d_pf, (size_t)groups * nchar)); QCHK(hipMalloc(&d_pl, (size_t)groups * nchar));
+  QCHK(hipMalloc(&d_first, (size_t)nchar)); QCHK(hipMalloc(&d_flags, (size_t)nchar));
+  QCHK(hipMemsetAsync(d_first, 'N', (size_t)nchar, st)); QCHK(hipMemsetAsync(d_flags, 0, (size_t)nchar, st));
+  hipEvent_t freed[2] = {nullptr, nullptr};
+  for (int i = 0; i < 2; i++) QCHK(hipEventCreateWithFlags(&freed[i], hipEventDisableTiming));
+  const unsigned gx = (unsigned)((hi - lo + 255) / 256);
+  int k = 0;
+  for (int a = 0; a < n_query; a += batch, k++) {
+    const int m = std::min(batch, n_query - a), b = k & 1;
+    if (k >= 2) QCHK(hipEventSynchronize(freed[b]));                 // the staging half's previous batch has been consumed
+    uint8_t *hb = h_rows + (size_t)b * batch * pitch, *db = d_rows + (size_t)b * batch * pitch;
+    for (int i = 0; i < m; i++) if (!seq[a + i]) { for (int j = 0; j < 2; j++) hipEventDestroy(freed[j]); return done(fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", a + i)); }
+    parallel_for(m, [&](int i) { memcpy(hb + (size_t)i * pitch, seq[a + i], (size_t)nchar); });
+    QCHK(hipMemcpyAsync(db, hb, (size_t)m * pitch, hipMemcpyHostToDevice, st));
+    const int ng = (m + 63) / 64;
+    hipLaunchKernelGGL(query_columns_partial_kernel, dim3(gx, (unsigned)ng), dim3(256), 0, st, db, pitch, m, lo, hi, acgt ? 1 : 0, d_pf, d_pl, nchar);
+    hipLaunchKernelGGL(query_columns_merge_kernel, dim3(gx), dim3(256), 0, st, d_pf, d_pl, ng, lo, hi, nchar, d_first, d_flags);
+    QCHK(hipGetLastError());
+    QCHK(hipEventRecord(freed[b], st));
+  }
+  std::vector<uint8_t> first((size_t)nchar), flags((size_t)nchar);
+  QCHK(hipMemcpyAsync(first.data(), d_first, (size_t)nchar, hipMemcpyDeviceToHost, st));
+  QCHK(hipMemcpyAsync(flags.data(), d_flags, (size_t)nchar, hipMemcpyDeviceToHost, st));
+  QCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < 2; i++) hipEventDestroy(freed[i]);
+#undef QCHK
+  for (int c = lo; c < hi; c++) {
+    consensus[c] = (flags[(size_t)c] & 1) ? '#' : (char)first[(size_t)c];
+    some_missing[c] = (flags[(size_t)c] & 2) ? 1 : 0;
+  }
+  return done(0);
+}
+
 int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, int n_ref, int64_t ordinal0, uint8_t *entered)
 {
   if (!c) return UVAIA_GPU_EINVAL;

@@ -46,7 +46,8 @@ typedef struct {
   int mismatch, gap_opening, gap_extension;      /* match is 0 (src/align.c:305); all > 0, mismatch and opening + extension below 64 */
   int min_wavefront_length;                      /* <= 0: complete wavefronts (no reduction) */
   int max_distance_threshold;
-  size_t workspace_bytes;                        /* device memory for the wavefronts of the queries in flight; 0 = chosen from the free memory */
+  size_t workspace_bytes;                        /* device memory for the wavefronts of the queries in flight; 0 = starts at 4 GB and grows,
+                                                    up to three quarters of the free memory, when queries find it exhausted */
   int max_blocks;                                /* queries in flight (one block of four wavefronts each); 0 = as many as the chip holds */
 } uvaia_align_options;
 

@@ -385,7 +385,7 @@ def test_truncated_consensus_prescore_is_reproduced():
 def test_random_small_many_states(acgt):
     """Many tiny problems with heavy ties and tiny heaps: exercises heap layout / tie handling / T dynamics."""
     rng = np.random.default_rng(5)
-    for it in range(12):
+    for it in range(8):
         L = int(rng.integers(40, 200))
         refs, root, cols = F.synth_alignment(int(rng.integers(5, 150)), L, seed=100 + it, p_snp=0.02, p_amb=0.01)
         qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=200 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)

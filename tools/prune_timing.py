@@ -17,6 +17,12 @@ for nq in sizes:
     base = hostlib.PreparedQuery(qseqs, names)
     t_plain = time.time() - t0
     row = {"queries": nq, "prepare_without_pruning_s": round(t_plain, 2)}
+    for mode in ("host", "device"):           # the column walk of create_query_indices alone decides these two
+        hostlib.set_prune_mode(mode)
+        t0 = time.time()
+        hostlib.PreparedQuery(qseqs, names)
+        row["prepare_without_pruning_columns_on_%s_s" % mode] = round(time.time() - t0, 3)
+    hostlib.set_prune_mode("auto")
     for mode in ("device", "host"):
         if mode == "host" and nq > 3000:
             continue                      # minutes

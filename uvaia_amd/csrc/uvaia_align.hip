@@ -492,27 +492,34 @@ int ensure_pool(uvaia_aligner *a, size_t bytes, int n)
   return 0;
 }
 
-int ensure_pool_memory(uvaia_aligner *a)
+// The workspace: with workspace_bytes == 0 it starts at 4 GB (a small job should not pay for mapping 200 GB) and grows by a factor
+// of four, up to three quarters of the free device memory, whenever a pass leaves queries that found the pool empty.
+int ensure_pool_memory(uvaia_aligner *a, bool grow, bool *grew)
 {
-  if (a->d_pool) return 0;
+  if (grew) *grew = false;
+  if (a->d_pool && !grow) return 0;
   // a chunk holds the ring of I and D wavefronts (e + 2 pairs of the widest wavefront, at most all plen + tlen + 1 diagonals of a
   // query of up to 1.5 reference lengths, src/align.c:199) and serves as the unit the queries' histories grow by
   const unsigned long long widest = (unsigned long long)a->plen * 5 / 2 + 64;
   int lg = 19;
   while ((1ull << lg) < (unsigned long long)(a->P.e + 2) * 2ull * widest) lg++;
   if (lg > 28) return afail(a, UVAIA_ALIGN_EINVAL, "reference of %d sites is too long for the wavefront workspace", a->plen);
-  const size_t chunk_bytes = (size_t)4 << lg;
+  const size_t chunk_bytes = (size_t)4 << lg, have = (size_t)a->n_chunks * chunk_bytes;
+  if (a->d_pool && a->workspace_request) return 0;                  // a workspace of a given size does not grow
   size_t free_b = 0, total_b = 0;
   ACHK(a, hipMemGetInfo(&free_b, &total_b));
-  size_t want = a->workspace_request ? a->workspace_request : free_b / 4 * 3;
-  want = std::min(want, (size_t)0xffffffffull * 64);              // array positions are kept in units of 64 bytes in 32 bits
+  const size_t cap = std::min((free_b + have) / 4 * 3, (size_t)0xffffffffull * 64);   // array positions are kept in units of 64 bytes in 32 bits
+  size_t want = a->workspace_request ? std::min(a->workspace_request, (size_t)0xffffffffull * 64) : std::min(cap, a->d_pool ? have * 4 : std::max((size_t)4 << 30, 8 * chunk_bytes));
+  if (a->d_pool && want <= have) return 0;                          // already as large as it gets
   size_t n_chunks = want / chunk_bytes;
   if (n_chunks < 3) return afail(a, UVAIA_ALIGN_ENOMEM, "workspace of %zu bytes is below three chunks of %zu bytes", want, chunk_bytes);
+  if (a->d_pool) { ACHK(a, hipStreamSynchronize(a->stream)); hipFree(a->d_pool); hipFree(a->d_ctl); hipFree(a->d_stack); a->d_pool = nullptr; a->d_ctl = nullptr; a->d_stack = nullptr; a->n_chunks = 0; }
   ACHK(a, hipMalloc(&a->d_pool, n_chunks * chunk_bytes));
   ACHK(a, hipMalloc(&a->d_ctl, sizeof(PoolCtl)));
   ACHK(a, hipMalloc(&a->d_stack, n_chunks * sizeof(int)));
   a->n_chunks = (int)n_chunks; a->chunk_log2 = lg;
   a->h_stack.resize(n_chunks);
+  if (grew) *grew = true;
   return 0;
 }
 
@@ -622,7 +629,7 @@ int uvaia_align_run(uvaia_aligner *a)
   ACHK(a, hipSetDevice(a->device));
   a->passes = 0; a->cells = 0; a->kernel_ms = 0; a->ran = false;
   if (a->n == 0) { a->ran = true; return 0; }
-  int rc = ensure_pool_memory(a); if (rc) return rc;
+  int rc = ensure_pool_memory(a, false, nullptr); if (rc) return rc;
   ACHK(a, hipMemsetAsync(a->d_cells, 0, sizeof(unsigned long long), a->stream));
   ACHK(a, hipEventRecord(a->ev_a, a->stream));
   // every block keeps two chunks for the whole launch; the rest of the pool is what the queries in flight share
@@ -650,6 +657,17 @@ int uvaia_align_run(uvaia_aligner *a)
       else if (status[(size_t)i] == ST_BACKTRACE) return afail(a, UVAIA_ALIGN_ESTATE, "sequence %d: inconsistent backtrace", i);
     }
     if (list.empty()) break;
+    {   // queries found the pool empty: a workspace of the library's choosing grows first, then fewer queries go in flight
+      bool grew = false;
+      rc = ensure_pool_memory(a, true, &grew); if (rc) return rc;
+      if (grew) {
+        ACHK(a, hipMemcpyAsync(a->d_todo, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, a->stream));
+        ACHK(a, hipStreamSynchronize(a->stream));
+        todo = a->d_todo; n_todo = (int)list.size();
+        blocks = std::max(1, std::min(std::min(n_todo, a->max_blocks), a->n_chunks / 3));
+        continue;
+      }
+    }
     if (blocks == 1) return afail(a, UVAIA_ALIGN_ENOMEM, "sequence %d needs more than the whole workspace (%zu bytes) for its wavefronts", list[0], ((size_t)a->n_chunks * 4) << a->chunk_log2);
     blocks = std::max(1, std::min((int)list.size(), blocks / 4));
     ACHK(a, hipMemcpyAsync(a->d_todo, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, a->stream));

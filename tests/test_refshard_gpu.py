@@ -67,15 +67,15 @@ def test_group_push_streams_batches_like_one_context(data, acgt):
 
 
 def test_group_at_benchmark_shape():
-    """generator data, 1 000 queries x 12 000 references x 29 903 columns, k = 100, four contexts: the regime of the 8-GPU run
+    """generator data, 1 000 queries x 8 000 references x 29 903 columns, k = 100, four contexts: the regime of the 8-GPU run
     (63 query tiles per scan, rare columns, 250 queries per replaying context)"""
     from uvaia_amd import hostlib
     gen = hostlib.Synth(29903, seed=20241008, preset=0)
     qs, _ = gen.generate_bytes(1 << 40, 1000)
     qn = _names(1000, "query_")
-    refs, _ = gen.generate_bytes(0, 12000)
+    refs, _ = gen.generate_bytes(0, 8000)
     oq = O.Query(qs, qn)
-    gold = O.search(oq, refs, _names(len(refs)), pool=12000, nbest=100, ambig_r=0.5)
+    gold = O.search(oq, refs, _names(len(refs)), pool=8000, nbest=100, ambig_r=0.5)
     pq = hostlib.PreparedQuery(qs, qn)
     with capi.Group(pq, [0, 0, 0, 0], nbest=100, max_pool=4096, piece_refs=1024) as g:
         g.db_reserve(len(refs))
@@ -83,7 +83,7 @@ def test_group_at_benchmark_shape():
             g.db_append(refs[a:a + 4000])
         g.reset()
         g.db_rederive()
-        ent = g.search_resident(12000)
+        ent = g.search_resident(8000)
         n, T, sc, od = g.drain()
     assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
     assert list(np.nonzero(ent)[0]) == list(gold.saved)

@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run GPU-vs-oracle check on the sample")
     ap.add_argument("--no-sweep", action="store_true", help="headline workload only (profiling runs)")
     ap.add_argument("--sweep-refs", type=int, default=1000000, help="references of the sweep entries")
+    ap.add_argument("--subslice", type=int, default=0, help="tuning: sub-slice length of the resident search in references (0 = the library's choice)")
     ap.add_argument("--rederive-streams", type=int, default=0, help="tuning: streams the chunks of uvaia_gpu_db_rederive alternate over (0 = the library's choice)")
     ap.add_argument("--align-queries", type=int, default=10000, help="queries of the uvaialign record (BASELINE config[4]; 0 = skip)")
     ap.add_argument("--align-only", action="store_true", help="only the uvaialign record (profiling runs); prints {\"align\": ...}")
@@ -480,7 +481,7 @@ def main():
         from uvaia_amd import refshard
         plan = refshard.Plan(world, rank, args.refs, pq.ntax, pool=args.pool)
         pool = plan.slice_refs
-    eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank, tuning=({"rederive_streams": args.rederive_streams} if args.rederive_streams else None))
+    eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank, tuning=({k: v for k, v in (("rederive_streams", args.rederive_streams), ("subslice_refs", args.subslice)) if v} or None))
     t_q2 = time.time()
     if args.qt:
         eng.set_query_tile(args.qt)

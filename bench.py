@@ -378,6 +378,37 @@ def parity_on_timed_path(O, capi, pq, gen, first, qseqs, qnames, mode, pool, nbe
                 and all(got[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(oq.ntax)))
 
 
+def parity_on_refshard(O, capi, refshard, dist, pq, gen, qseqs, qnames, mode, nbest, world, rank, device, on_gpu):
+    """N > 1: a sample of the stream through the protocol the timed step runs -- reference shards, pieces of two tiles so that there
+    are several stripes, the exchange over the process group in use (RCCL on the node) -- and every rank compares the heaps and
+    tolerances of its own query shard with the oracle's; the verdict is the AND over the ranks."""
+    import torch
+    piece, per_rank = 128, 256
+    n_s = per_rank * world
+    plan = refshard.Plan(world, rank, per_rank, pq.ntax, pool=None, piece=piece)
+    sample, _ = gen.generate_bytes(0, n_s)
+    oq = O.Query(qseqs, qnames, acgt=(mode == "acgt"))
+    gold = O.search(oq, sample, ["ref_%d" % i for i in range(n_s)], pool=n_s, nbest=nbest, ambig_r=0.5)
+    ok = True
+    with pq.open_engine(nbest=nbest, max_pool=plan.slice_refs, device=device) as e2:
+        e2.db_set_shard(rank, world, plan.piece)
+        e2.db_reserve(n_s)
+        rows, non_n = gen.generate(0, n_s)
+        e2.db_append_block(rows, non_n)
+        x2 = refshard.TorchExchange(dist, plan, e2, "cuda" if on_gpu else "cpu", pinned=not on_gpu)
+        e2.reset()
+        e2.db_rederive()
+        refshard.run(e2, plan, x2, len(pq.idx_c) > 0)
+        e2.sync()
+        n, T, sc, od = e2.drain()
+        got = capi.finalise_heaps(n, sc, od)
+        for iq in range(plan.q0, plan.q1):
+            ok = ok and got[iq] == [(tuple(s_), o) for o, _, s_ in gold.rows[iq]] and int(T[iq]) == gold.final_T[iq]
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()) == 1)
+
+
 def emulate_refshard(args):
     """N contexts on one GPU run the protocol an N-GPU run uses (uvaia_gpu_group_*): every context derives and scans its pieces of the
     N x --refs references against all queries, the rows of each query shard are copied to the context that replays them.  The
@@ -591,6 +622,10 @@ def main():
             cpu = cpu_baseline(O, gen, first, qseqs, qnames, args.mode, pool, args.nbest, args.cpu_warm, args.cpu_refs, args.cpu_refs_1thread)
         if not args.no_parity:
             parity = parity_on_timed_path(O, capi, pq, gen, first, qseqs, qnames, args.mode, pool, args.nbest, min(args.parity_refs, args.refs), local_rank, args.qt)
+    if world > 1 and multi == "refshard" and not args.no_parity:      # every rank takes part; the oracle is the checker, as at N = 1
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        parity = parity_on_refshard(O, capi, refshard, dist, pq, gen, qseqs, qnames, args.mode, args.nbest, world, rank, local_rank, on_gpu)
     eng.close()
 
     # ---- other resident-query counts, driver-timed in the same run (rank 0, N=1 only)

@@ -18,7 +18,7 @@ from uvaia_amd import capi  # noqa: E402
 
 def one(rng, k):
     nchar = rng.choice([61, 128, 333, 777, 1024, 2500, 4097])
-    nq = rng.choice([1, 3, 16, 17, 40, 64, 65, 100, 150, 257])
+    nq = rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 17, 40, 64, 65, 100, 150, 257])
     nref = rng.choice([70, 300, 1000, 2500])
     acgt = rng.random() < 0.5
     trim = rng.choice([0, 0, 7, min(230, nchar // 4)])
@@ -26,7 +26,7 @@ def one(rng, k):
     pool = rng.choice([64, 97, 333, 1000, nref])
     tuning = {"rare_max": rng.choice([0, -1, 1, 3, 50]), "subslice_refs": rng.choice([0, 64, 256]),
               "scan_tiles_per_wave": rng.choice([0, 1, 2]), "scan_waves_per_block": rng.choice([0, 4, 8]),
-              "scan": rng.choice(["auto", "auto", "compressed"])}          # <= 16 queries scan the packed planes unless told otherwise
+              "rederive_streams": rng.choice([0, 1, 2]), "scan": rng.choice(["auto", "auto", "compressed"])}          # <= 16 queries scan the packed planes unless told otherwise
     p_snp = rng.choice([0.002, 0.006, 0.02])
     refs, root, cols = F.synth_alignment(nref, nchar, seed=1000 + k, p_snp=p_snp)
     qs, _, _ = F.synth_alignment(nq, nchar, seed=5000 + k, root=root, poly_cols=cols, p_snp=p_snp)
@@ -61,6 +61,35 @@ def one(rng, k):
     return desc, bool(ok)
 
 
+def one_alignment_set(rng, k):
+    """the aligner of uvaialign: random reference length, divergence, penalties and reduction settings against the oracle"""
+    from uvaia_amd import align
+    L = rng.choice([1, 7, 64, 300, 1500, 6000])
+    ref = F.random_acgt(L, 9000 + k)
+    seqs = F.unaligned_queries(ref, rng.choice([1, 5, 40]), 9500 + k, p_snp=rng.choice([0.001, 0.02, 0.2]), p_indel=rng.choice([0.0002, 0.01]), max_indel=rng.choice([3, 12, 60]),
+                               n_runs=(rng.choice([0, 30]), rng.choice([0, 30]), rng.choice([0, 40, 400])), run_prob=0.6, ambiguity=0.002)
+    opts = rng.choice([{}, {}, dict(min_wavefront_length=0), dict(mismatch=3, gap_opening=5, gap_extension=1), dict(mismatch=5, gap_opening=2, gap_extension=3),
+                       dict(min_wavefront_length=10, max_distance_threshold=rng.choice([5, 50]))])
+    d = align.default_options()
+    pen = (0, opts.get("mismatch", d.mismatch), opts.get("gap_opening", d.gap_opening), opts.get("gap_extension", d.gap_extension))
+    ok = True
+    with align.Aligner(ref, workspace_bytes=rng.choice([0, 64 << 20, 1 << 30]), **opts) as al:
+        score, rows = al.align(seqs)
+    for i, t in enumerate(seqs):
+        want, cigar, _, _ = O.wfa_align(ref, t, penalties=pen, min_wavefront_length=opts.get("min_wavefront_length", d.min_wavefront_length),
+                                        max_distance_threshold=opts.get("max_distance_threshold", d.max_distance_threshold))
+        row, pos = bytearray(), 0
+        for op in cigar:
+            if op in b"MX":
+                row.append(t[pos]); pos += 1
+            elif op == ord("I"):
+                pos += 1
+            else:
+                row.append(ord("-"))
+        ok &= int(score[i]) == want and rows[i].tobytes() == bytes(row)
+    return dict(aligner=True, L=L, n=len(seqs), **opts), bool(ok)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
@@ -69,7 +98,7 @@ def main():
     rng = random.Random(a.seed)
     bad = 0
     for k in range(a.n):
-        desc, ok = one(rng, k + 100 * a.seed)
+        desc, ok = one_alignment_set(rng, k + 100 * a.seed) if k % 5 == 4 else one(rng, k + 100 * a.seed)
         print(("ok   " if ok else "FAIL ") + str(desc), flush=True)
         bad += not ok
     print("%d of %d configurations failed" % (bad, a.n))

@@ -857,6 +857,10 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define BIGHEAP(A, B, PF_) OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<A, B, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    BIGHEAP(true, true, 1); BIGHEAP(true, false, 1); BIGHEAP(false, true, 1); BIGHEAP(false, false, 1);
+    BIGHEAP(true, true, 2); BIGHEAP(true, false, 2); BIGHEAP(false, true, 2); BIGHEAP(false, false, 2);
+#undef BIGHEAP
   }
 #undef OPENCHK
   int rc = uvaia_gpu_reset(c);
@@ -1481,11 +1485,17 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   const int2 *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
-#define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
+#define REPLAY2P(A, B, PF_) hipLaunchKernelGGL((replay2_kernel<A, B, PF_>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
                                   (c->scan_variant == 2 && c->shard_world == 1) ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
-  if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
-  else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
+  // Candidates of a tile whose on-demand counters are requested ahead.  The bookkeeping of the request slots costs more than the
+  // latency it hides (measured on one box: config[1] 3.69 / 3.54 / 3.60 ms per step with 3 / 2 / 1, 4 queries x 1 M references
+  // 4.37 / 4.03 / 3.89; with 6 or 8 over 7 ms): two for large query sets, one -- request, then use -- for a handful of queries.
+  const int pf = (q1 - q0) <= 64 ? 1 : 2;
+#define REPLAY2(A, B) { if (pf == 1) REPLAY2P(A, B, 1); else REPLAY2P(A, B, 2); }
+  if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true) else REPLAY2(true, false) }
+  else         { if (c->n_idx_c > 0) REPLAY2(false, true) else REPLAY2(false, false) }
+#undef REPLAY2P
 #undef REPLAY2
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->replay_done[buf], c->stream));

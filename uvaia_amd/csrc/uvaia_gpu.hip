@@ -217,6 +217,28 @@ static void parallel_for(int n, F f)
   for (auto &x : th) x.join();
 }
 
+// Buffers of a streamed batch (uvaia_gpu_push, uvaia_gpu_ball, uvaia_gpu_agree_on_polymorphic): packed tiles of max_pool references,
+// the planes derived from them, side rows.  A context that only searches a resident database never needs them.
+int ensure_batch_buffers(uvaia_gpu_ctx *c)
+{
+  if (c->d_batch) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t tile_u4 = (size_t)c->W4 * c->P * 64, tiles = c->pool_pad / 64;
+  HIPCHK(c, hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_batch_ev, tiles * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_batch_grp, tiles * (size_t)c->W4 * 64 * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc(&c->d_batch_poly, tiles * (size_t)std::max(c->NP4 + c->NR4, 1) * 3 * 64 * sizeof(uint4)));
+  HIPCHK(c, hipMalloc(&c->d_batch_tote, c->pool_pad * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_ROW * sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_ROW * sizeof(int)));
+  HIPCHK(c, hipMalloc(&c->d_batch, tiles * tile_u4 * sizeof(uint4)));       // last: its presence says all of them are there
+  HIPCHK(c, hipMemset(c->d_batch, 0, tiles * tile_u4 * sizeof(uint4)));
+  return 0;
+}
+
 // Packs one character row restricted to `keep` (nullable: keep everything inside [lo,hi)) into query-plane words:
 // dst[(w4*4 + j)*NQ + plane].  is_poly marks query->idx columns (--acgt: fourth plane).
 int pack_query_row(const uint8_t *code_tab, const char *row, int nchar, int lo, int hi, const uint8_t *keep, const uint8_t *is_poly,
@@ -819,19 +841,8 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   OPENCHK(hipMalloc(&c->d_err, sizeof(int)));
   OPENCHK(hipMemset(c->d_err, 0, sizeof(int)));
   // ---- batch buffers
-  const size_t tile_u4 = (size_t)c->W4 * c->P * 64;
-  OPENCHK(hipMalloc(&c->d_batch, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
-  OPENCHK(hipMemset(c->d_batch, 0, (c->pool_pad / 64) * tile_u4 * sizeof(uint4)));
-  OPENCHK(hipMalloc(&c->d_batch_nonn, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMemset(c->d_batch_nonn, 0, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMalloc(&c->d_batch_ev, (c->pool_pad / 64) * (size_t)c->W4 * 2 * 64 * sizeof(uint4)));
-  OPENCHK(hipMalloc(&c->d_batch_grp, (c->pool_pad / 64) * (size_t)c->W4 * 64 * sizeof(uint32_t)));
-  OPENCHK(hipMalloc(&c->d_batch_poly, (c->pool_pad / 64) * (size_t)std::max(c->NP4 + c->NR4, 1) * 3 * 64 * sizeof(uint4)));
-  OPENCHK(hipMalloc(&c->d_batch_tote, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMalloc(&c->d_batch_tot, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMemset(c->d_batch_tot, 0, c->pool_pad * sizeof(int)));
-  OPENCHK(hipMalloc(&c->d_batch_amb, c->pool_pad * AMB_ROW * sizeof(int)));
-  OPENCHK(hipMemset(c->d_batch_amb, 0, c->pool_pad * AMB_ROW * sizeof(int)));
+  // (the buffers of a streamed batch -- packed tiles, their derived planes, side rows: 25 KB per reference of max_pool -- are allocated
+  // by the first call that streams sequences in: ensure_batch_buffers)
   if (!c->fullscan) { OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2))); c->slice_cap[0] = (size_t)c->nq_pad * c->pool_pad; }
   OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   OPENCHK(hipMalloc(&c->d_rtb[0], c->pool_pad * sizeof(int4)));
@@ -920,7 +931,8 @@ int uvaia_gpu_agree_on_polymorphic(uvaia_gpu_ctx *c, const char *const *seq, int
   if (n_seq < 0 || (n_seq > 0 && (!seq || !out))) return fail(c, UVAIA_GPU_EINVAL, "bad batch");
   if ((size_t)n_seq > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_seq, c->max_pool);
   if (n_seq == 0) return 0;
-  int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_seq, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
+  int rc = ensure_batch_buffers(c); if (rc) return rc;
+  rc = pack_rows(c, seq, nullptr, 0, nullptr, n_seq, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
   const int n_tiles = (n_seq + 63) / 64, ppad = n_tiles * 64;
   rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
@@ -1006,7 +1018,8 @@ int uvaia_gpu_push(uvaia_gpu_ctx *c, const char *const *seq, const int *non_n, i
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
   if (c->act_q0 != 0 || c->act_q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "streamed batches act on the whole query set: query shards use the resident calls");
   if (n_ref == 0) return 0;
-  int rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
+  int rc = ensure_batch_buffers(c); if (rc) return rc;
+  rc = pack_rows(c, seq, nullptr, 0, non_n, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
   const int n_tiles = (n_ref + 63) / 64;
   HIPCHK(c, hipMemsetAsync(c->d_entered, 0, (size_t)n_tiles * 64, c->stream));
@@ -1945,7 +1958,8 @@ int uvaia_gpu_ball(uvaia_gpu_ctx *c, const char *const *seq, int n_ref, int radi
   if ((size_t)n_ref > c->max_pool) return fail(c, UVAIA_GPU_ESTATE, "batch of %d exceeds max_pool %zu", n_ref, c->max_pool);
   if (c->act_q0 != 0 || c->act_q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "the radius search acts on the whole query set");
   if (n_ref == 0) return 0;
-  int rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
+  int rc = ensure_batch_buffers(c); if (rc) return rc;
+  rc = pack_rows(c, seq, nullptr, 0, nullptr, n_ref, c->d_batch, c->d_batch_nonn, c->d_batch_amb, c->d_batch_tot, 0);
   if (rc) return rc;
   return ball_range(c, c->d_batch, 0, (n_ref + 63) / 64, 0, n_ref, radius, mindist);
 }

@@ -973,7 +973,9 @@ int uvaia_gpu_query_columns(const char *const *seq, int n_query, int nchar, size
   uint8_t *h_rows = nullptr, *d_rows = nullptr, *d_pf = nullptr, *d_pl = nullptr, *d_first = nullptr, *d_flags = nullptr;
   hipStream_t st = nullptr;
   hipError_t e = hipSuccess;
-  auto done = [&](int rc) { if (st) hipStreamDestroy(st); hipFree(d_rows); hipFree(d_pf); hipFree(d_pl); hipFree(d_first); hipFree(d_flags); if (h_rows) hipHostFree(h_rows); return rc; };
+  hipEvent_t freed[2] = {nullptr, nullptr};
+  auto done = [&](int rc) { if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); } for (int i = 0; i < 2; i++) if (freed[i]) hipEventDestroy(freed[i]);
+                            hipFree(d_rows); hipFree(d_pf); hipFree(d_pl); hipFree(d_first); hipFree(d_flags); if (h_rows) hipHostFree(h_rows); return rc; };
 #define QCHK(call) do { e = (call); if (e != hipSuccess) return done(fail(nullptr, e == hipErrorOutOfMemory ? UVAIA_GPU_ENOMEM : UVAIA_GPU_EHIP, "%s failed: %s", #call, hipGetErrorString(e))); } while (0)
   QCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   QCHK(hipHostMalloc(&h_rows, (size_t)2 * batch * pitch, hipHostMallocDefault));
@@ -981,7 +983,6 @@ int uvaia_gpu_query_columns(const char *const *seq, int n_query, int nchar, size
   QCHK(hipMalloc(&d_pf, (size_t)groups * nchar)); QCHK(hipMalloc(&d_pl, (size_t)groups * nchar));
   QCHK(hipMalloc(&d_first, (size_t)nchar)); QCHK(hipMalloc(&d_flags, (size_t)nchar));
   QCHK(hipMemsetAsync(d_first, 'N', (size_t)nchar, st)); QCHK(hipMemsetAsync(d_flags, 0, (size_t)nchar, st));
-  hipEvent_t freed[2] = {nullptr, nullptr};
   for (int i = 0; i < 2; i++) QCHK(hipEventCreateWithFlags(&freed[i], hipEventDisableTiming));
   const unsigned gx = (unsigned)((hi - lo + 255) / 256);
   int k = 0;
@@ -989,7 +990,7 @@ int uvaia_gpu_query_columns(const char *const *seq, int n_query, int nchar, size
     const int m = std::min(batch, n_query - a), b = k & 1;
     if (k >= 2) QCHK(hipEventSynchronize(freed[b]));                 // the staging half's previous batch has been consumed
     uint8_t *hb = h_rows + (size_t)b * batch * pitch, *db = d_rows + (size_t)b * batch * pitch;
-    for (int i = 0; i < m; i++) if (!seq[a + i]) { for (int j = 0; j < 2; j++) hipEventDestroy(freed[j]); return done(fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", a + i)); }
+    for (int i = 0; i < m; i++) if (!seq[a + i]) return done(fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", a + i));
     parallel_for(m, [&](int i) { memcpy(hb + (size_t)i * pitch, seq[a + i], (size_t)nchar); });
     QCHK(hipMemcpyAsync(db, hb, (size_t)m * pitch, hipMemcpyHostToDevice, st));
     const int ng = (m + 63) / 64;
@@ -1002,7 +1003,6 @@ int uvaia_gpu_query_columns(const char *const *seq, int n_query, int nchar, size
   QCHK(hipMemcpyAsync(first.data(), d_first, (size_t)nchar, hipMemcpyDeviceToHost, st));
   QCHK(hipMemcpyAsync(flags.data(), d_flags, (size_t)nchar, hipMemcpyDeviceToHost, st));
   QCHK(hipStreamSynchronize(st));
-  for (int i = 0; i < 2; i++) hipEventDestroy(freed[i]);
 #undef QCHK
   for (int c = lo; c < hi; c++) {
     consensus[c] = (flags[(size_t)c] & 1) ? '#' : (char)first[(size_t)c];

@@ -67,7 +67,7 @@ int uvaia_gpu_open (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_
 
 /* The same with tuning.  Every field 0 = the library's own choice; the values change speed, never results (the library reads no
  * environment variables). */
-enum { UVAIA_GPU_SCAN_AUTO = 0,        /* by query count: packed planes up to 16 queries, column-compressed above */
+enum { UVAIA_GPU_SCAN_AUTO = 0,        /* by query count: packed planes up to 32 queries, column-compressed above */
        UVAIA_GPU_SCAN_PACKED = 1,      /* two-counter scan straight over the packed planes (nothing derived per query set) */
        UVAIA_GPU_SCAN_COMPRESSED = 2,  /* column-compressed scan over planes derived for the query set */
        UVAIA_GPU_SCAN_WIDE = 3 };      /* four 32-bit counters per pair (what alignments above 49 000 columns get) */
@@ -271,8 +271,8 @@ int    uvaia_gpu_db_append_packed (uvaia_gpu_ctx *ctx, const void *planes, const
 
 /* bytes the pair scan reads per reference (the default scan reads planes derived from the packed record for this query set) */
 size_t uvaia_gpu_scan_bytes_per_ref (const uvaia_gpu_ctx *ctx);
-/* the pair scan of this context: 2 = column-compressed scan over planes derived for the query set (default above 16 queries),
- * 0 = two-counter scan straight over the packed planes (default up to 16 queries: nothing is derived), -1 = four-counter scan
+/* the pair scan of this context: 2 = column-compressed scan over planes derived for the query set (default above 32 queries),
+ * 0 = two-counter scan straight over the packed planes (default up to 32 queries: nothing is derived), -1 = four-counter scan
  * (alignments above 49 000 columns) */
 int uvaia_gpu_scan_variant (const uvaia_gpu_ctx *ctx);
 /* bytes per reference uvaia_gpu_db_rederive writes (the planes that depend on the query set; the appends also write the

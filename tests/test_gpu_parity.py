@@ -281,9 +281,9 @@ def test_rederive_is_idempotent_and_scan_shapes_agree(acgt, tuning):
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-@pytest.mark.parametrize("nq", [5, 16])
+@pytest.mark.parametrize("nq", [5, 16, 32])
 def test_small_query_sets_on_either_scan(acgt, nq):
-    """Up to 16 queries the engine scans the packed planes directly (two-counter kernels with tile bounds); the column-compressed
+    """Up to 32 queries the engine scans the packed planes directly (two-counter kernels with tile bounds); the column-compressed
     scan can be forced and must give the same heaps.  Both against the oracle, streamed and resident."""
     refs, root, cols = F.synth_alignment(900, 2100, seed=51)
     qs, _, _ = F.synth_alignment(nq, 2100, seed=151, root=root, poly_cols=cols)
@@ -314,7 +314,7 @@ def test_long_alignments_take_the_wide_counter_scan():
 
 @pytest.mark.parametrize("acgt", [False, True])
 def test_packed_plane_scan_with_many_query_tiles(synth, acgt):
-    """tuning.scan = packed: the two-counter scan over the packed planes (what up to 16 queries get) on 40 queries = three query tiles"""
+    """tuning.scan = packed: the two-counter scan over the packed planes (what up to 32 queries get) on 40 queries = three query tiles"""
     refs, qs = synth
     _assert_same_search(O.Query(qs, _names(len(qs), "q"), acgt=acgt), refs[:400], 100, 6, tuning={"scan": "packed"})
 

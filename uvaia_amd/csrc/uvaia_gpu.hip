@@ -543,9 +543,10 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   c->W = (c->nchar + 31) / 32; c->W4 = (c->W + 3) / 4;
   c->k = heap_size < 2 ? 2 : heap_size;                      // src/min_heap.c:58
   c->qt = c->nq <= 8 ? 8 : 16;
-  // One query tile: the column-compressed scan would move 25 KB per reference (building its planes) to read 1-8 KB; the
-  // two-counter scan over the packed planes reads each reference once (15 KB) and needs nothing derived.
-  c->scan_variant = tn.scan == UVAIA_GPU_SCAN_PACKED ? 0 : tn.scan == UVAIA_GPU_SCAN_COMPRESSED ? 2 : (c->nq <= 16 ? 0 : 2);
+  // Up to two query tiles: the column-compressed scan would move 25 KB per reference (building its planes) to read 1-8 KB; the
+  // two-counter scan over the packed planes reads each reference once per query tile (15 KB) and needs nothing derived (DESIGN.md
+  // 4.1; measured per 1 M references: 16 queries 5.3 ms against 8.8, 32 queries 8.2 against 9.8, 64 queries 12.6 against 8.9).
+  c->scan_variant = tn.scan == UVAIA_GPU_SCAN_PACKED ? 0 : tn.scan == UVAIA_GPU_SCAN_COMPRESSED ? 2 : (c->nq <= 32 ? 0 : 2);
   c->fullscan = tn.scan == UVAIA_GPU_SCAN_WIDE;
   c->serial = tn.serial != 0;
   if (tn.scan_tiles_per_wave) c->scan_R = tn.scan_tiles_per_wave;

@@ -191,7 +191,7 @@ int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
  * batch snapshot cq->max_incompatible = max over ALL heaps (src/nearest.c:290-291), which matters only when the query set has
  * constant-and-complete columns (n_idx_c > 0): then the driver runs pool by pool, all-reduces (max) uvaia_gpu_max_tolerance()
  * over the ranks and passes the result as `snapshot`.
- *   set_active_queries: resident and slice calls act on queries [q0, q1) only (q0 a multiple of 64: the scan's super-tile of queries); push/ball need the full range
+ *   set_active_queries: resident and slice calls act on queries [q0, q1) only (q0 a multiple of 64: the scan's super-tile of queries; any q0 under reference shards, where the range only selects tolerances); push/ball need the full range
  *   search_resident_pool: one batch [first, first+n) of the resident database, n <= max_pool; snapshot < 0 = take it from this
  *                         context's active queries */
 int uvaia_gpu_set_active_queries (uvaia_gpu_ctx *ctx, int q0, int q1);

@@ -99,3 +99,19 @@ def test_a_group_of_one_is_a_plain_context(data):
         n, T, sc, od = g.drain()
     assert capi.finalise_heaps(n, sc, od) == _want(gold, q.ntax) and list(T) == gold.final_T
     assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+def test_tolerance_range_may_start_anywhere_under_reference_shards(data):
+    """uvaia_amd/refshard.py asks every rank for the largest tolerance of ITS queries (the batch snapshot, src/nearest.c:290-291) by
+    narrowing the active range: 24 queries on two ranks give the range [16, 24).  A range that is scanned must start at a super-tile
+    of 64 queries; under reference shards every scan covers all queries and the range only selects tolerances."""
+    refs, qs, _ = data
+    q = O.Query(qs[:24], _names(24, "q"))
+    with capi.Engine.from_query(q, nbest=5, max_pool=256) as eng:
+        with pytest.raises(capi.GpuError):
+            eng.set_active_queries(16, 24)
+    with capi.Engine.from_query(q, nbest=5, max_pool=256) as eng:
+        eng.db_set_shard(1, 2, 128)
+        eng.set_active_queries(16, 24)
+        assert isinstance(eng.max_tolerance(), int)
+        eng.set_active_queries(0, 24)

@@ -1526,8 +1526,10 @@ int uvaia_gpu_slice_replay(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, int stri
 int uvaia_gpu_set_active_queries(uvaia_gpu_ctx *c, int q0, int q1)
 {
   if (!c) return UVAIA_GPU_EINVAL;
-  if (q0 < 0 || q1 > c->nq || q1 <= q0 || (q0 % 64)) return fail(c, UVAIA_GPU_EINVAL, "active queries [%d,%d): need 0 <= q0 < q1 <= %d and q0 a multiple of 64", q0, q1, c->nq);
-  // (with reference shards the range only selects whose tolerances uvaia_gpu_max_tolerance looks at: every scan covers all queries)
+  // (with reference shards the range only selects whose tolerances uvaia_gpu_max_tolerance looks at -- every scan covers all queries --
+  // and may start anywhere; a range that is scanned starts at a super-tile of 64 queries)
+  if (q0 < 0 || q1 > c->nq || q1 <= q0 || ((q0 % 64) && c->shard_world == 1))
+    return fail(c, UVAIA_GPU_EINVAL, "active queries [%d,%d): need 0 <= q0 < q1 <= %d and q0 a multiple of 64", q0, q1, c->nq);
   if ((c->fullscan || c->scan_variant != 2) && c->shard_world == 1) { if (q0 != 0 || q1 != c->nq) return fail(c, UVAIA_GPU_ESTATE, "query shards need the default scan"); }
   c->act_q0 = q0; c->act_q1 = q1;
   return 0;

@@ -466,10 +466,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: refusing to report a line for a different number of ranks" % (world, args.gpus))
-    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
-        # torch.distributed.run pins every rank to one OpenMP thread; the host library (generator, query preparation) and the checker
-        # are OpenMP code loaded below: give each rank its share of the host's cores instead
-        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
 
     import torch
     from uvaia_amd import capi, hostlib

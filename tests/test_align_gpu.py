@@ -186,3 +186,33 @@ def test_uvaialign_cli_against_the_committed_snapshot(tmp_path):
     got_names, got_rows = F.read_fasta_bytes(r.stdout)
     assert got_names == [q["name"] for q in snap["queries"]]
     assert [hashlib.sha1(x).hexdigest() for x in got_rows] == [q["row_sha1"] for q in snap["queries"]]
+
+
+def test_a_query_that_is_half_N_equals_oracle():
+    """the most ambiguous query the filter of src/align.c:204-212 lets through (49 % N in three long runs): a score near 60 000, wavefronts
+    wider than the 2 560 diagonals that stay in LDS (those steps read their sources from memory), 57 M cells = 270 MB of history"""
+    ref = F.random_acgt(29903, 7)
+    q = bytearray(ref)
+    for a, n in ((100, 6000), (9000, 5000), (20000, 3600)):
+        q[a:a + n] = b"N" * n
+    q = bytes(q)
+    assert O.uvaialign_accepts(q, len(ref))
+    with align.Aligner(ref) as al:
+        score = _check(ref, [q, ref], al)
+        assert score[0] > 55000 and score[1] == 0
+        assert al.stats()["cells"] > 50_000_000
+
+
+@pytest.mark.parametrize("opts", [dict(min_wavefront_length=0), dict(min_wavefront_length=3000, max_distance_threshold=2000)])
+def test_wavefronts_wider_than_the_lds_ring_equal_oracle(opts):
+    """complete (or barely reduced) wavefronts over a run of 2 000 N: widths far above the 2 560 diagonals kept in LDS, so steps read
+    sources that never were in LDS, sources that were (the narrow steps before) and write their own I/D wavefronts to memory"""
+    ref = F.random_acgt(8000, 71)
+    q = bytearray(ref)
+    q[3000:5000] = b"N" * 2000
+    q = bytes(q[:6500] + q[6510:])
+    d = align.default_options()
+    kw = dict(penalties=(0, d.mismatch, d.gap_opening, d.gap_extension), min_wavefront_length=opts["min_wavefront_length"],
+              max_distance_threshold=opts.get("max_distance_threshold", d.max_distance_threshold))
+    with align.Aligner(ref, **opts) as al:
+        _check(ref, [q, ref[:7000]], al, **kw)

@@ -129,10 +129,10 @@ struct uvaia_gpu_ctx {
   size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
   uint32_t *d_cpm = nullptr;     // consensus restricted to idx_m (radius search)
-  uint32_t *d_qpoly = nullptr;   // queries restricted to idx (radius search), [nq_pad][W4][4][NQ]
+  uint32_t *d_qpoly = nullptr;   // queries restricted to idx (radius search, redundancy test), [nq_pad][W4][4][NQ]: d_qp masked by d_pmask, built by the first call that needs it
+  uint32_t *d_pmask = nullptr;   // [W4*4] mask of the polymorphic query columns (query->idx)
   int *d_mindist = nullptr, *d_ball_list = nullptr, *d_ball_cdist = nullptr, *d_ball_n = nullptr; size_t ball_cap = 0;   // radius search: results, the references that go on to the queries
   uint4 *d_ball_tiles = nullptr; size_t ball_tiles_cap = 0; unsigned long long ball_asked = 0;
-  std::vector<uint32_t> h_qp_poly_src;  // kept to build d_qpoly lazily
   // heaps / state
   int *d_heap = nullptr, *d_n = nullptr, *d_T = nullptr, *d_snap = nullptr, *d_err = nullptr;
   // batch buffers
@@ -215,6 +215,32 @@ static void parallel_for(int n, F f)
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { for (;;) { const int a = next.fetch_add(4); if (a >= n) break; for (int i = a; i < std::min(n, a + 4); i++) f(i); } });
   for (auto &x : th) x.join();
+}
+
+// Query planes restricted to the polymorphic columns (query->idx): what the radius search and the redundancy test compare references
+// with.  Packing a query row with every other site left out gives its full planes under the mask of those columns, so they are made
+// on the device from d_qp by the first call that needs them.
+__global__ void mask_query_planes_kernel(const uint32_t *__restrict__ qp, const uint32_t *__restrict__ pmask, uint32_t *__restrict__ out, size_t n_words_total, int words_per_row, int nq_planes)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_words_total) return;
+  const int w = (int)((i / (size_t)nq_planes) % (size_t)words_per_row);       // layout [query][word][plane]
+  out[i] = qp[i] & pmask[w];
+}
+
+int ensure_qpoly(uvaia_gpu_ctx *c)
+{
+  if (c->d_qpoly) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->nq_pad * c->W4 * 4 * c->NQ;
+  uint32_t *d = nullptr;
+  HIPCHK(c, hipMalloc(&d, n * 4));
+  hipLaunchKernelGGL(mask_query_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_qp, c->d_pmask, d, n, c->W4 * 4, c->NQ);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { hipFree(d); return fail(c, UVAIA_GPU_EHIP, "query planes on the polymorphic columns: %s", hipGetErrorString(e)); }
+  c->d_qpoly = d;
+  return 0;
 }
 
 // Buffers of a streamed batch (uvaia_gpu_push, uvaia_gpu_ball, uvaia_gpu_agree_on_polymorphic): packed tiles of max_pool references,
@@ -498,7 +524,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   void *dev[] = {c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
-                 c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
+                 c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_pmask, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -584,15 +610,14 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   for (int i = 0; i < q->n_idx_c; i++) if (q->idx_c[i] < (size_t)c->nchar) in_c[q->idx_c[i]] = 1;
   for (int i = 0; i < q->n_idx_m; i++) if (q->idx_m[i] < (size_t)c->nchar) in_m[q->idx_m[i]] = 1;
   for (int i = 0; i < q->n_idx; i++)   if (q->idx[i]   < (size_t)c->nchar) in_p[q->idx[i]] = 1;
-  std::vector<uint32_t> qp((size_t)c->nq_pad * row_words, 0u), cp(row_words, 0u), cpm(row_words, 0u), qpoly((size_t)c->nq_pad * row_words, 0u);
+  std::vector<uint32_t> qp((size_t)c->nq_pad * row_words, 0u), cp(row_words, 0u), cpm(row_words, 0u);
   int bad = 0;
   for (int i = 0; i < c->nq; i++) if (!q->seq[i]) { uvaia_gpu_close(c); return fail(nullptr, UVAIA_GPU_EINVAL, "query %d is NULL", i); }
   {
     std::atomic<int> first_bad(c->nq);
     std::vector<int> bad_byte((size_t)c->nq, 0);
     parallel_for(c->nq, [&](int i) {
-      if (pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, nullptr, in_p.data(), c->acgt, c->NQ, qp.data() + (size_t)i * row_words, &bad_byte[(size_t)i]) ||
-          pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, in_p.data(), in_p.data(), c->acgt, c->NQ, qpoly.data() + (size_t)i * row_words, &bad_byte[(size_t)i])) {
+      if (pack_query_row(code_tab, q->seq[i], c->nchar, lo, hi, nullptr, in_p.data(), c->acgt, c->NQ, qp.data() + (size_t)i * row_words, &bad_byte[(size_t)i])) {
         int cur = first_bad.load();
         while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
       }
@@ -830,7 +855,11 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     }
     OPENCHK(hipMalloc(&c->d_amb_q, ambq.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_amb_q, ambq.data(), ambq.size() * sizeof(int), hipMemcpyHostToDevice));
   }
-  OPENCHK(hipMalloc(&c->d_qpoly, qpoly.size() * 4)); OPENCHK(hipMemcpy(c->d_qpoly, qpoly.data(), qpoly.size() * 4, hipMemcpyHostToDevice));
+  {  // the queries restricted to query->idx are the query planes under the mask of those columns: kept as the mask (ensure_qpoly)
+    std::vector<uint32_t> pmask((size_t)c->W4 * 4, 0u);
+    for (int sidx = lo; sidx < hi; sidx++) if (in_p[(size_t)sidx]) pmask[(size_t)sidx >> 5] |= 1u << (sidx & 31);
+    OPENCHK(hipMalloc(&c->d_pmask, pmask.size() * 4)); OPENCHK(hipMemcpy(c->d_pmask, pmask.data(), pmask.size() * 4, hipMemcpyHostToDevice));
+  }
   OPENCHK(hipMalloc(&c->d_cp, cp.size() * 4)); OPENCHK(hipMemcpy(c->d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cpm, cpm.size() * 4)); OPENCHK(hipMemcpy(c->d_cpm, cpm.data(), cpm.size() * 4, hipMemcpyHostToDevice));
 
@@ -938,6 +967,7 @@ int uvaia_gpu_agree_on_polymorphic(uvaia_gpu_ctx *c, const char *const *seq, int
   const int n_tiles = (n_seq + 63) / 64, ppad = n_tiles * 64;
   rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
   const bool prof = c->profile; c->profile = false;     // not the nearest-neighbour scan the statistics describe
+  rc = ensure_qpoly(c); if (rc) return rc;
   rc = launch_scan(c, c->d_batch, 0, n_tiles, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
   c->profile = prof;
   if (rc) return rc;
@@ -1941,6 +1971,7 @@ static int ball_range(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first
     HIPCHK(c, hipGetLastError());
     int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
     const bool prof = c->profile; c->profile = false;     // not the nearest-neighbour scan the statistics describe
+    rc = ensure_qpoly(c); if (rc) return rc;
     rc = launch_scan(c, c->d_ball_tiles, 0, mt, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
     c->profile = prof;
     if (rc) return rc;

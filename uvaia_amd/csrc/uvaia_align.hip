@@ -10,8 +10,10 @@
 //     A query is a chain of thousands of dependent steps (one per score); N-rich sequences (the normal SARS-CoV-2 case) make
 //     the wavefronts 1 000-2 000 diagonals wide for most of them, so a step has work for 256 lanes and one barrier.
 //   * lane = diagonal.  A step computes I, D, M of 256 diagonals at a time from the wavefronts of score - e, score - o - e,
-//     score - x, extends M along the diagonal in registers (byte compares; long runs are extended by the whole wave, 256
-//     characters per round trip) and stores M once.  Reference and queries are read through L2.
+//     score - x, extends M along the diagonal in registers (eight characters per lane in one unaligned 8-byte compare; longer
+//     runs by the whole wave, 1 024 characters per round trip) and stores M once.  Reference and queries are read through L2.
+//   * the wavefronts a step reads are those of the last few steps: they stay in LDS (16-bit offsets, up to 2 560 diagonals) and
+//     the stores to the history in memory are not waited for; wider wavefronts and unusual penalties fall back to memory.
 //   * what is kept for the backtrace is 5 bytes per cell, not 12: the M offset and one provenance byte (which of the five
 //     predecessors gave the maximum, in the backtrace's tie order; whether the I and the D cell extend or open).  I and D
 //     offsets only feed the next e scores and live in a ring chunk.  A ring of the last 64 headers lives in LDS.

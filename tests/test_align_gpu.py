@@ -162,6 +162,8 @@ def test_uvaialign_cli_matches_oracle(tmp_path):
     subprocess.run(cmd + ["-o", str(tmp_path / "out")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     with lzma.open(tmp_path / "out.aln.xz", "rb") as fh:
         assert fh.read() == r.stdout
+    r2 = subprocess.run(cmd + ["--stdout", "--devices", "0,0,0"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)   # three aligners on one GPU
+    assert r2.stdout == r.stdout and b"aligned on 3 GPUs" in r2.stderr
 
 
 def test_uvaialign_cli_against_the_committed_snapshot(tmp_path):

@@ -11,18 +11,20 @@
 
 #include "cli_common.h"
 #include "fastaseq.h"
+#include "gpu_glue.h"
 #include "../../../include/uvaia_align.h"
 
 int
 main (int argc, char **argv)
 {
   int help = 0, version = 0, to_screen = 0, pool = 256 * omp_get_max_threads (), device = 0, errors = 0, n_fasta = 0, ch;   /* src/align.c:59-63 */
+  int devices[64], n_devices = 0;
   double ambig = 0.5;
   const char *out = NULL, *ref_file = NULL;
   static const struct option longopts[] = {
     {"help", no_argument, 0, 'h'}, {"version", no_argument, 0, 'v'}, {"stdout", no_argument, 0, 1000}, {"ambiguity", required_argument, 0, 'a'},
     {"pool", required_argument, 0, 'p'}, {"reference", required_argument, 0, 'r'}, {"nthreads", required_argument, 0, 't'},
-    {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1001}, {0, 0, 0, 0}};
+    {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1001}, {"devices", required_argument, 0, 1002}, {0, 0, 0, 0}};
   while ((ch = getopt_long (argc, argv, "hva:p:r:t:o:", longopts, NULL)) != -1) switch (ch) {
     case 'h': help = 1; break;
     case 'v': version = 1; break;
@@ -33,6 +35,7 @@ main (int argc, char **argv)
     case 't': break;                                  /* the alignments run on the GPU: host threads do not matter */
     case 'o': out = optarg; break;
     case 1001: device = atoi (optarg); break;
+    case 1002: n_devices = uvaia_parse_device_list (optarg, devices, 64); if (!n_devices) { fprintf (stderr, "--devices: expected a list such as 0-7 or 0,2,3\n"); exit (EXIT_FAILURE); } break;
     default: errors++;
   }
   const char **fasta = (const char **) argv + optind;
@@ -50,6 +53,7 @@ main (int argc, char **argv)
     printf ("  -r, --reference=<ref.fa|ref.fa.xz> reference sequence in fasta format, possibly compressed with gz, xz, bz2\n");
     printf ("  <seqs.fa|seqs.fa.xz>             sequences to align in fasta format, possibly compressed with gz, xz, bz2 (can be multiple files)\n");
     printf ("  --device=<int>                   GPU to use (default 0)\n");
+    printf ("  --devices=<list>                 several GPUs, e.g. 0-7 or 0,2,3: every pool of queries is cut among them (same rows as one GPU)\n");
     if (help) {
       printf ("Based on the wavefront algorithm (WFA, https://github.com/smarco/WFA), computed on the GPU.\n");
       printf ("Since the sequences are assumed to be similar, sequences too short or too big w.r.t. the reference are rejected.\n\n");
@@ -82,9 +86,13 @@ main (int argc, char **argv)
   const size_t aln_length = rfas->seqlength;
   del_readfasta (rfas);
   if (aln_length > 0x3fffffff) biomcmc_error ("reference sequence of %zu sites is too long", aln_length);
-  uvaia_aligner *gpu = NULL;
-  if (uvaia_align_open (&gpu, refseq, (int) aln_length, device, NULL)) biomcmc_error ("%s", uvaia_align_last_error (NULL));
-  fprintf (stderr, "Batches of %d sequences will be read and aligned on GPU %d.\n", pool, device);
+  /* alignments of different queries do not depend on each other: with several GPUs every pool is cut into contiguous shares, one
+     aligner and one host thread per GPU (replicas of src/align.c's per-thread aligners, no exchange) */
+  if (!n_devices) { n_devices = 1; devices[0] = device; }
+  uvaia_aligner *gpu[64];
+  for (int d = 0; d < n_devices; d++) if (uvaia_align_open (&gpu[d], refseq, (int) aln_length, devices[d], NULL)) biomcmc_error ("%s", uvaia_align_last_error (NULL));
+  if (n_devices > 1) fprintf (stderr, "Batches of %d sequences will be read and aligned on %d GPUs.\n", pool, n_devices);
+  else fprintf (stderr, "Batches of %d sequences will be read and aligned on GPU %d.\n", pool, devices[0]);
 
   file_compress_t outstream = to_screen ? NULL : biomcmc_open_compress (outfilename, "w");
   char **seq = (char **) biomcmc_malloc ((size_t) pool * sizeof (char *)), **name = (char **) biomcmc_malloc ((size_t) pool * sizeof (char *));
@@ -126,7 +134,16 @@ main (int argc, char **argv)
         fill++;
       }
       if (fill) {
-        if (uvaia_align_batch (gpu, (const char *const *) seq, len, fill, aln, NULL)) biomcmc_error ("%s", uvaia_align_last_error (gpu));
+        int failed = -1;
+#pragma omp parallel for num_threads(n_devices) schedule(static, 1)
+        for (int d = 0; d < n_devices; d++) {
+          const int a = (int) ((long long) fill * d / n_devices), b = (int) ((long long) fill * (d + 1) / n_devices);
+          if (b > a && uvaia_align_batch (gpu[d], (const char *const *) seq + a, len + a, b - a, aln + (size_t) a * (aln_length + 1), NULL)) {
+#pragma omp critical
+            failed = d;
+          }
+        }
+        if (failed >= 0) biomcmc_error ("%s", uvaia_align_last_error (gpu[failed]));
         for (int c = 0; c < fill; c++) {
           const char *row = aln + (size_t) c * (aln_length + 1);
           n_output++;
@@ -149,7 +166,7 @@ main (int argc, char **argv)
     biomcmc_close_compress (outstream);
     fprintf (stderr, "Saved %d sequences to file %s\nTotal elapsed time: %.3lf secs\n", n_output, outfilename, biomcmc_update_elapsed_time (time0));
   }
-  uvaia_align_close (gpu);
+  for (int d = 0; d < n_devices; d++) uvaia_align_close (gpu[d]);
   free (seq); free (name); free (len); free (aln); free (refseq); free (outfilename);
   return EXIT_SUCCESS;
 }

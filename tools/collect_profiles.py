@@ -27,7 +27,8 @@ def main():
                      ("q4/q4_kernel_stats.csv", "r02_q4_1Mrefs_kernel_stats.csv"), ("q4/q4_kernel_trace.csv", "r02_q4_1Mrefs_kernel_trace.csv"),
                      ("hbm_read.txt", "r02_hbm_read_ceiling.txt"), ("push_rate.json", "r02_push_rate.json"), ("ingest.json", "r02_ingest_text_vs_packed.json"),
                      ("emu_refshard_2.json", "r02_emulated_reference_shards_2.json"), ("emu_refshard_4.json", "r02_emulated_reference_shards_4.json"),
-                     ("emu_refshard_8.json", "r02_emulated_reference_shards_8.json")):
+                     ("emu_refshard_8.json", "r02_emulated_reference_shards_8.json"), ("align_cli.json", "r02_uvaialign_cli_10k.json"),
+                     ("prune_timing.txt", "r02_query_preparation_timing.txt")):
         if os.path.exists(os.path.join(M, src)):
             shutil.copyfile(os.path.join(M, src), os.path.join(P, dst))
     if not os.path.exists(os.path.join(M, "pmc_summary.json")):

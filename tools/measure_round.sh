@@ -3,9 +3,10 @@
 #   a = the default bench.py run (config[1] + sweep + ball), kernel statistics and PMC passes of the config[1] step
 #   b = --acgt config[1], the Q = 4 kernel timeline, push-path and ingest timings
 #   c = reference-shard emulation (2, 4, 8 contexts on one GPU)
+#   d = uvaialign: SQ counters of the aligner, the command line end to end; query preparation timings
 # (parts so that each fits one gpurun call; tools/collect_profiles.py turns the results into profiles/r02_*)
 set -o pipefail
-PART=${1:-abc}
+PART=${1:-abcd}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/measure; mkdir -p $O
 step() { echo "== $*"; }
@@ -30,5 +31,10 @@ step ingest;         timeout -k 10 600 python tools/ingest_bench.py --refs 10000
 fi
 if [[ $PART == *c* ]]; then
 for n in 2 4 8; do step emulated reference shards $n; timeout -k 10 500 python bench.py --emulate-refshard $n --steps 5 --warmup 1 > $O/emu_refshard_$n.json 2> $O/emu_refshard_$n.err || exit 1; done
+fi
+if [[ $PART == *d* ]]; then
+step aligner counters;  bash tools/profile_align.sh > $O/align_prof.log 2>&1 || exit 1
+step uvaialign cli;     timeout -k 10 600 python tools/align_cli_bench.py > $O/align_cli.json 2> $O/align_cli.err || exit 1
+step query preparation; timeout -k 10 300 python tools/prune_timing.py 3000 10000 > $O/prune_timing.txt 2>&1 || exit 1
 fi
 echo done

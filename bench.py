@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--no-sweep", action="store_true", help="headline workload only (profiling runs)")
     ap.add_argument("--sweep-refs", type=int, default=1000000, help="references of the sweep entries")
     ap.add_argument("--scan", choices=["auto", "packed", "compressed"], default="auto", help="tuning: which pair scan the engine runs (auto: packed planes up to 32 queries)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE", help="any other field of uvaia_gpu_tuning (repeatable), e.g. scan_waves_per_block=4")
     ap.add_argument("--subslice", type=int, default=0, help="tuning: sub-slice length of the resident search in references (0 = the library's choice)")
     ap.add_argument("--rederive-streams", type=int, default=0, help="tuning: streams the chunks of uvaia_gpu_db_rederive alternate over (0 = the library's choice)")
     ap.add_argument("--align-queries", type=int, default=10000, help="queries of the uvaialign record (BASELINE config[4]; 0 = skip)")
@@ -513,7 +514,8 @@ def main():
         from uvaia_amd import refshard
         plan = refshard.Plan(world, rank, args.refs, pq.ntax, pool=args.pool)
         pool = plan.slice_refs
-    eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank, tuning=({k: v for k, v in (("rederive_streams", args.rederive_streams), ("subslice_refs", args.subslice), ("scan", args.scan if args.scan != "auto" else 0)) if v} or None))
+    eng = pq.open_engine(nbest=args.nbest, max_pool=pool, device=local_rank, tuning=({k: v for k, v in (("rederive_streams", args.rederive_streams), ("subslice_refs", args.subslice), ("scan", args.scan if args.scan != "auto" else 0))
+                                      + tuple((kv.split("=", 1)[0], int(kv.split("=", 1)[1])) for kv in args.tuning) if v} or None))
     t_q2 = time.time()
     if args.qt:
         eng.set_query_tile(args.qt)

@@ -7,6 +7,5 @@ CMD="python bench.py --align-only --align-queries 2000 --align-cpu-queries 0 --s
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o a --output-format csv -- $CMD > $O/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM -d $O/sqa -o a --output-format csv -- $CMD > $O/sqa.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS -d $O/sqb -o b --output-format csv -- $CMD > $O/sqb.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE -d $O/mem -o m --output-format csv -- $CMD > $O/mem.log 2>&1 || exit 1
-python tools/pmc_summary.py a=$(ls $O/sqa/*counter_collection.csv) b=$(ls $O/sqb/*counter_collection.csv) m=$(ls $O/mem/*counter_collection.csv) > $O/summary.json
+python tools/pmc_summary.py sq_a=$(ls $O/sqa/*counter_collection.csv) sq_b=$(ls $O/sqb/*counter_collection.csv) > $O/summary.json || exit 1
 echo done

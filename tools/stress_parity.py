@@ -73,8 +73,15 @@ def one_alignment_set(rng, k):
     d = align.default_options()
     pen = (0, opts.get("mismatch", d.mismatch), opts.get("gap_opening", d.gap_opening), opts.get("gap_extension", d.gap_extension))
     ok = True
-    with align.Aligner(ref, workspace_bytes=rng.choice([0, 64 << 20, 1 << 30]), **opts) as al:
-        score, rows = al.align(seqs)
+    table = L * pen[1] + pen[2] + 2 * L * pen[3]          # scores the reference's aligner has wavefronts for (src/align.c:306-309)
+    try:
+        with align.Aligner(ref, workspace_bytes=rng.choice([0, 64 << 20, 1 << 30]), **opts) as al:
+            score, rows = al.align(seqs)
+    except align.AlignError as e:                          # refused: right only if some sequence does score above the table
+        i = int(str(e).split("sequence ")[1].split(":")[0]) if "alignment score above" in str(e) else -1
+        over = i >= 0 and O.wfa_align(ref, seqs[i], penalties=pen, min_wavefront_length=opts.get("min_wavefront_length", d.min_wavefront_length),
+                                      max_distance_threshold=opts.get("max_distance_threshold", d.max_distance_threshold))[0] > table
+        return dict(aligner=True, L=L, n=len(seqs), refused="score above the table", **opts), bool(over)
     for i, t in enumerate(seqs):
         want, cigar, _, _ = O.wfa_align(ref, t, penalties=pen, min_wavefront_length=opts.get("min_wavefront_length", d.min_wavefront_length),
                                         max_distance_threshold=opts.get("max_distance_threshold", d.max_distance_threshold))
@@ -94,11 +101,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--aligner-only", action="store_true", help="every configuration is an aligner set")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     bad = 0
     for k in range(a.n):
-        desc, ok = one_alignment_set(rng, k + 100 * a.seed) if k % 5 == 4 else one(rng, k + 100 * a.seed)
+        desc, ok = one_alignment_set(rng, k + 100 * a.seed) if (k % 5 == 4 or a.aligner_only) else one(rng, k + 100 * a.seed)
         print(("ok   " if ok else "FAIL ") + str(desc), flush=True)
         bad += not ok
     print("%d of %d configurations failed" % (bad, a.n))

@@ -12,8 +12,11 @@
 //   * lane = diagonal.  A step computes I, D, M of 256 diagonals at a time from the wavefronts of score - e, score - o - e,
 //     score - x, extends M along the diagonal in registers (eight characters per lane in one unaligned 8-byte compare; longer
 //     runs by the whole wave, 1 024 characters per round trip) and stores M once.  Reference and queries are read through L2.
+//     A wave takes its diagonals two groups of 64 at a time and asks for the characters of both before it compares either.
 //   * the wavefronts a step reads are those of the last few steps: they stay in LDS (16-bit offsets, up to 2 560 diagonals) and
 //     the stores to the history in memory are not waited for; wider wavefronts and unusual penalties fall back to memory.
+//     The step is compiled twice: the usual one, whose wavefront and sources are all in LDS, carries none of the bookkeeping of
+//     the fallbacks (the kernel is bound by instruction issue: what a step executes besides its cells is what it costs).
 //   * what is kept for the backtrace is 5 bytes per cell, not 12: the M offset and one provenance byte (which of the five
 //     predecessors gave the maximum, in the backtrace's tie order; whether the I and the D cell extend or open).  I and D
 //     offsets only feed the next e scores and live in a ring chunk.  A ring of the last 64 headers lives in LDS.
@@ -33,10 +36,18 @@
 
 #include "../../include/uvaia_align.h"
 
+// build-time shape (tools/ab_align.sh measures variants): groups of 64 diagonals a wave has in flight, waves per block
+#ifndef WFA_GROUP
+#define WFA_GROUP 2
+#endif
+#ifndef WFA_NW
+#define WFA_NW 4
+#endif
+
 namespace {
 
 constexpr int WFA_NULL = -10;            // offset of a diagonal a wavefront does not hold (oracle/wfa_oracle.c)
-constexpr int NW = 4;                    // waves per block = per query
+constexpr int NW = WFA_NW;               // waves per block = per query
 constexpr int TPB = 64 * NW;
 constexpr int RING = 64;                 // scores whose headers stay in LDS; penalties are below this
 constexpr int HDR_INTS = 8;
@@ -49,6 +60,7 @@ enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3, ST_TOOWIDE
 enum { C_DEL_EXT = 0, C_DEL_OPEN = 1, C_INS_EXT = 2, C_INS_OPEN = 3, C_MISMATCH = 4, C_I_EXT = 8, C_D_EXT = 16 };
 
 struct WfaParams { int x, oe, e, min_wf_len, max_dist_thr, max_score, g; };
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // Workspace: chunks of 2^chunk_log2 words handed out from a stack under a spin lock (one thread of a block at a time, the others
 // wait at a barrier; a query takes a chunk every few hundred thousand cells).  Block b owns chunks 2b (first history chunk) and
@@ -71,6 +83,19 @@ __device__ __forceinline__ int matching_prefix8(const uint8_t *a, const uint8_t 
   __builtin_memcpy(&x, a, 8); __builtin_memcpy(&y, b, 8);
   const unsigned long long d = x ^ y;
   return d ? (int)(__builtin_ctzll(d) >> 3) : 8;
+}
+
+// minimum over the wave by DPP (row shifts, then row broadcasts): six VALU steps, no trip through the LDS crossbar
+__device__ __forceinline__ int wave_min_dpp(int v)
+{
+  const int big = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xF, 0xF, false));    // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xF, 0xF, false));    // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xF, 0xF, false));    // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xF, 0xF, false));    // row_shr:8  -> lane 15 of every row holds the row's minimum
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xA, 0xF, false));    // row_bcast:15 into rows 1 and 3
+  v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xC, 0xF, false));    // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // barrier for steps whose wavefronts are exchanged through LDS only: the stores to the history in memory stay in flight
@@ -98,6 +123,9 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
   const int chunk_log2 = ctl->chunk_log2;
   const unsigned chunk_words = 1u << chunk_log2;
   const size_t home_base = (size_t)(2 * blockIdx.x) << chunk_log2, ring_base = (size_t)(2 * blockIdx.x + 1) << chunk_log2;
+  // the I and D wavefronts a step reads are those of score - e, at most e / gcd steps back: more of them than LDS slots, and every step
+  // keeps a copy of its I and D in memory
+  const bool id_deep = P.e / P.g >= RID;
   unsigned long long cells_total = 0;
 
   for (;;) {
@@ -119,7 +147,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
     unsigned cur_used = 0, ring_pos = 0, widest16 = 16;
     int n_own = 0;
     unsigned long long cells = 0;
-    int score = 0, status = ST_OK, step = 0;
+    int score = 0, status = ST_OK, step = 0, cslot = 0, cislot = 0;      // cslot = step mod RM, cislot = step mod RID
     bool reached = false;
 
     auto take = [&](unsigned words, size_t &at) -> bool {    // `words` (a multiple of 16, at most a chunk) of the query's memory; false = the pool is empty
@@ -165,7 +193,8 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         auto load = [&](int s, Hdr &h) {
           if (s < 0) { h.flags = 0; return; }
           const int *r = ring[s & (RING - 1)];            // the same for every lane: kept in scalar registers
-          h.lo = rfl(r[0]); h.hi = rfl(r[1]); h.lo_base = rfl(r[2]); h.flags = rfl(r[3]); h.off16 = (uint32_t)rfl(r[4]); h.w = rfl(r[5]); h.id16 = (uint32_t)rfl(r[6]); h.res = rfl(r[7]);
+          // (where the arrays lie in memory -- off16, w, id16 -- is looked up only by a step that has to read a source from there)
+          h.lo = rfl(r[0]); h.hi = rfl(r[1]); h.lo_base = rfl(r[2]); h.flags = rfl(r[3]); h.res = rfl(r[7]);
         };
         load(score - P.x, hs); load(score - P.oe, hg); load(score - P.e, he);
         const bool n_sub = !(hs.flags & 1), n_gap = !(hg.flags & 1), n_i = !(he.flags & 2), n_d = !(he.flags & 4);
@@ -184,31 +213,50 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         const bool has_i = score > 0 && ((hg.flags & 1) || (he.flags & 2)), has_d = score > 0 && ((hg.flags & 1) || (he.flags & 4));
         const int w = hi - lo + 1, w16 = w16_of(w);
         const unsigned hist_words = (unsigned)w16 + (unsigned)w16_of((w + 3) / 4);
-        // the ring chunk keeps the I and D wavefronts of the last e + 1 steps: e + 2 pairs of the widest one must fit (one is lost to the wrap)
-        widest16 = max(widest16, (unsigned)w16);
-        if ((unsigned long long)(P.e + 2) * 2ull * widest16 > chunk_words || hist_words > chunk_words) { status = ST_TOOWIDE; break; }
-        size_t m_at = 0;
-        if (!take(hist_words, m_at)) { status = ST_OVERFLOW; break; }
-        if (ring_pos + 2u * (unsigned)w16 > chunk_words) ring_pos = 0;
-        const size_t id_at = ring_base + ring_pos;
-        ring_pos += 2u * (unsigned)w16;
-        cells += (unsigned)w;
         // where the wavefronts of this step and of its sources live
-        const bool resident = w <= WL && tlen + step + 32 < 65535;          // offsets grow by at most one per step beyond tlen
-        const bool id_to_memory = !resident || P.e >= RID;                  // (more existing scores between s - e and s than LDS slots: keep a copy)
-        const int cslot = step % RM, cislot = step % RID;
-        const bool lds_s = hs.res && step - (hs.res - 1) < RM, lds_g = hg.res && step - (hg.res - 1) < RM, lds_e = he.res && step - (he.res - 1) < RID;
-        const int slot_s = hs.res ? (hs.res - 1) % RM : 0, slot_g = hg.res ? (hg.res - 1) % RM : 0, slot_e = he.res ? (he.res - 1) % RID : 0;
-        const bool all_lds = (!(hs.flags & 1) || lds_s) && (!(hg.flags & 1) || lds_g) && (!(he.flags & 6) || lds_e);
+        const bool fits = w <= WL && tlen + step + 32 < 65535;              // offsets grow by at most one per step beyond tlen
+        // LDS slots: this step's (cslot, cislot: step mod RM, step mod RID, kept as running counters) and, d steps back, its sources'
+        const int d_s = step - (hs.res - 1), d_g = step - (hg.res - 1), d_e = step - (he.res - 1);
+        const bool lds_s = hs.res && d_s < RM, lds_g = hg.res && d_g < RM, lds_e = he.res && d_e < RID;
+        const int slot_s = lds_s ? (cslot >= d_s ? cslot - d_s : cslot - d_s + RM) : 0, slot_g = lds_g ? (cslot >= d_g ? cslot - d_g : cslot - d_g + RM) : 0;
+        const int slot_e = lds_e ? (cislot >= d_e ? cislot - d_e : cislot - d_e + RID) : 0;
+        const bool sources_in_lds = (!(hs.flags & 1) || lds_s) && (!(hg.flags & 1) || lds_g) && (!(he.flags & 6) || lds_e);
+        // The step proper, compiled twice.  LDS_ONLY: the usual step -- this wavefront fits in LDS, so do all it reads, and I and D need no
+        // copy in memory: nothing but the history of the backtrace leaves the CU, and none of the bookkeeping of the other kind of step
+        // (positions in the ring chunk, pointers to sources in memory, which of them to wait for) is executed.  Returns true when the
+        // forward pass has to stop (status set).
+        auto step_body = [&](auto lds_only_tag) -> bool {
+        constexpr bool LDS_ONLY = decltype(lds_only_tag)::value;
+        const bool resident = LDS_ONLY || fits;
+        size_t id_at = 0;
+        if (!LDS_ONLY) {
+          // the ring chunk keeps the I and D wavefronts of the last e + 1 steps: e + 2 pairs of the widest one must fit (one is lost to the wrap)
+          widest16 = max(widest16, (unsigned)w16);
+          if ((unsigned long long)(P.e + 2) * 2ull * widest16 > chunk_words || hist_words > chunk_words) { status = ST_TOOWIDE; return true; }
+          if (ring_pos + 2u * (unsigned)w16 > chunk_words) ring_pos = 0;
+          id_at = ring_base + ring_pos;
+          ring_pos += 2u * (unsigned)w16;
+        }
+        size_t m_at = 0;
+        if (!take(hist_words, m_at)) { status = ST_OVERFLOW; return true; }
+        cells += (unsigned)w;
+        const bool id_to_memory = !LDS_ONLY && (!resident || id_deep);      // (more existing scores between s - e and s than LDS slots: keep a copy)
+        const bool all_lds = LDS_ONLY || sources_in_lds;
         // a source that left LDS is read from memory, where its step wrote it without waiting: make those stores complete first
-        if (((hs.flags & 1) && hs.res && !lds_s) || ((hg.flags & 1) && hg.res && !lds_g) || ((he.flags & 6) && he.res && !lds_e)) __syncthreads();
+        if (!LDS_ONLY && (((hs.flags & 1) && hs.res && !lds_s) || ((hg.flags & 1) && hg.res && !lds_g) || ((he.flags & 6) && he.res && !lds_e))) __syncthreads();
         uint32_t *out_m = pool + m_at, *out_i = pool + id_at, *out_d = out_i + w16;
         uint8_t *out_c = reinterpret_cast<uint8_t *>(out_m + w16);
-        const uint32_t *ms = pool + ((size_t)hs.off16 << 4) - hs.lo_base, *mg = pool + ((size_t)hg.off16 << 4) - hg.lo_base;
-        const uint32_t *ie = pool + ((size_t)he.id16 << 4) - he.lo_base, *de = ie + w16_of(he.w);
+        // sources in memory (a step that is not all_lds): M of score - x, M of score - o - e, I and D of score - e
+        auto mem_m = [&](int s_, const Hdr &h_) -> const uint32_t * { return pool + ((size_t)(uint32_t)ring[s_ & (RING - 1)][4] << 4) - h_.lo_base; };
+        auto mem_i = [&](int s_, const Hdr &h_) -> const uint32_t * { return pool + ((size_t)(uint32_t)ring[s_ & (RING - 1)][6] << 4) - h_.lo_base; };
         int min_distance = max(plen, tlen);
         bool hit_end = false;
-        for (int k0 = lo + 64 * wave; k0 <= hi; k0 += TPB) {
+        // A cell in two halves.  front: its offset before the extension (five offsets from LDS, I and D stored) and the request for the
+        // first eight characters of either sequence; back: the extension and the stores.  A wave takes its diagonals WFA_GROUP x 64 at
+        // a time, all fronts before the first back: one LDS and one memory round trip per group instead of one per 64 diagonals.
+        struct Cell { int k, m; unsigned code; bool act, go; unsigned long long x, y; };
+        auto front = [&](int k0) -> Cell {
+          Cell c;
           const int k = k0 + lane;
           const bool act = k <= hi;
           int m = 0;
@@ -222,6 +270,8 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
               const int a_s = (int)lm[slot_s][xs] - 16, a_m = (int)lm[slot_g][xm] - 16, a_p = (int)lm[slot_g][xp] - 16, a_i = (int)li[slot_e][xi] - 16, a_d = (int)ld[slot_e][xd] - 16;
               r_s = in_s ? a_s : WFA_NULL; r_gm = in_gm ? a_m : WFA_NULL; r_gp = in_gp ? a_p : WFA_NULL; r_i = in_i ? a_i : WFA_NULL; r_d = in_d ? a_d : WFA_NULL;
             } else {
+              const uint32_t *ms = (hs.flags & 1) && !lds_s ? mem_m(score - P.x, hs) : pool, *mg = (hg.flags & 1) && !lds_g ? mem_m(score - P.oe, hg) : pool;
+              const uint32_t *ie = (he.flags & 6) && !lds_e ? mem_i(score - P.e, he) : pool, *de = ie + ((he.flags & 6) && !lds_e ? w16_of(ring[(score - P.e) & (RING - 1)][5]) : 0);
               r_s  = in_s  ? (lds_s ? (int)lm[slot_s][k - hs.lo_base] - 16     : (int)ms[k])     : WFA_NULL;
               r_gm = in_gm ? (lds_g ? (int)lm[slot_g][k - 1 - hg.lo_base] - 16 : (int)mg[k - 1]) : WFA_NULL;
               r_gp = in_gp ? (lds_g ? (int)lm[slot_g][k + 1 - hg.lo_base] - 16 : (int)mg[k + 1]) : WFA_NULL;
@@ -237,16 +287,26 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
             code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
           }
-          // exact extension along the diagonal (paper algorithm 2): eight characters per lane in one round trip, longer runs by the
-          // whole wave, 1 024 characters per round trip (the loads may run up to seven bytes past a sequence: both buffers are padded)
-          int v = m - k, h = m;
-          bool go = act && (unsigned)h < (unsigned)tlen && (unsigned)v < (unsigned)plen;
-          if (__any(go)) {
-            int nmat = 0;
-            if (go) nmat = min(matching_prefix8(ref + v, text + h), min(plen - v, tlen - h));
+          // exact extension along the diagonal (paper algorithm 2): eight characters per lane in one round trip (the loads may run up to
+          // seven bytes past a sequence: both buffers are padded) ...
+          const int v = m - k, h = m;
+          c.k = k; c.m = m; c.code = code; c.act = act;
+          c.go = act && (unsigned)h < (unsigned)tlen && (unsigned)v < (unsigned)plen;
+          c.x = 0ull; c.y = 0ull;
+          if (c.go) { __builtin_memcpy(&c.x, ref + v, 8); __builtin_memcpy(&c.y, text + h, 8); }
+          return c;
+        };
+        auto back = [&](const Cell &c, int k0) {
+          const int k = c.k;
+          int m = c.m, v = m - k, h = m;
+          bool go = c.go;
+          {   // (no branch around this: a wait for the characters that a path can skip makes the next cells wait for this cell's stores)
+            const unsigned long long d = c.x ^ c.y;
+            const int nmat = go ? min(d ? (int)(__builtin_ctzll(d) >> 3) : 8, min(plen - v, tlen - h)) : 0;
             v += nmat; h += nmat; m += nmat;
             go = go && nmat == 8 && v < plen && h < tlen;
           }
+          // ... longer runs by the whole wave, 1 024 characters per round trip
           unsigned long long more = __ballot(go);
           while (more) {
             const int j = __builtin_ctzll(more);
@@ -268,19 +328,26 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             }
             if (lane == j) m += ext;
           }
-          const int dk_ = act ? dist_to_end(plen, tlen, m, k) : 0x7fffffff;
+          const int dk_ = c.act ? dist_to_end(plen, tlen, m, k) : 0x7fffffff;
           if (k0 == lo) dend[step & 1][0][lane] = dk_;
           if (k0 + 64 > hi) dend[step & 1][1][lane] = dk_;
-          if (act) {
+          if (c.act) {
             if (resident) lm[cslot][k - lo] = (uint16_t)(m + 16);
             out_m[k - lo] = (uint32_t)m;
-            out_c[k - lo] = (uint8_t)code;
+            out_c[k - lo] = (uint8_t)c.code;
             min_distance = min(min_distance, dk_);
             if (k == alignment_k && m >= tlen) hit_end = true;
           }
-        }
+        };
+        for (int k0 = lo + 64 * wave; k0 <= hi; k0 += WFA_GROUP * TPB) {
+          Cell c[WFA_GROUP];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) min_distance = min(min_distance, __shfl_xor(min_distance, o));
+          for (int g = 0; g < WFA_GROUP; g++) if (k0 + g * TPB <= hi) c[g] = front(k0 + g * TPB);
+          __builtin_amdgcn_sched_barrier(0);                   // (the scheduler would pair every front with its back again)
+#pragma unroll
+          for (int g = 0; g < WFA_GROUP; g++) if (k0 + g * TPB <= hi) back(c[g], k0 + g * TPB);
+        }
+        min_distance = wave_min_dpp(min_distance);
         const bool wave_hit = __any(hit_end);
         if (lane == 0) { wsync[step & 1][wave][0] = min_distance; wsync[step & 1][wave][1] = wave_hit ? 1 : 0; }
         if (resident) lds_barrier(); else __syncthreads();      // the one barrier of a step: offsets stored by other waves are read from here on
@@ -325,6 +392,10 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
           ring_out[lane] = val;
           if (wave == 0) hdr_out[lane] = val;
         }
+        cslot = cslot + 1 == RM ? 0 : cslot + 1; cislot = cislot + 1 == RID ? 0 : cislot + 1;
+        return false;
+        };
+        if ((fits && sources_in_lds && !id_deep) ? step_body(BoolTag<true>()) : step_body(BoolTag<false>())) break;
       }
       if (reached) break;
       score += P.g;                                             // scores that are no multiple of gcd(x, o + e, e) have no wavefront (and no header: never looked up)
@@ -426,7 +497,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         pool_unlock(ctl);
       }
     }
-    cells_total += cells;
+    if (status == ST_OK) cells_total += cells;                   // (a query that is run again is counted by the pass that completes it)
     __syncthreads();
   }
   if (tid == 0 && cells_total) atomicAdd(cells_out, cells_total);
@@ -522,6 +593,54 @@ int ensure_pool_memory(uvaia_aligner *a, bool grow, bool *grew)
   a->n_chunks = (int)n_chunks; a->chunk_log2 = lg;
   a->h_stack.resize(n_chunks);
   if (grew) *grew = true;
+  return 0;
+}
+
+// The kernel over all queries of the pool, then again over those that found the workspace empty, until none is left.
+int run_passes(uvaia_aligner *a)
+{
+  int n_todo = a->n;
+  int blocks = std::max(1, std::min(std::min(n_todo, a->max_blocks), a->n_chunks / 3));
+  const int *todo = nullptr;
+  std::vector<int> status((size_t)a->n), list, todo_list;             // todo_list empty: all queries of the pool
+  for (;;) {
+    // every block keeps two chunks for the whole launch; the rest of the pool is what the queries in flight share
+    const PoolCtl ctl{0, a->n_chunks - 2 * blocks, a->n_chunks, a->chunk_log2};
+    for (int i = 0; i < ctl.top; i++) a->h_stack[(size_t)i] = 2 * blocks + i;
+    ACHK(a, hipMemcpyAsync(a->d_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice, a->stream));
+    if (ctl.top > 0) ACHK(a, hipMemcpyAsync(a->d_stack, a->h_stack.data(), (size_t)ctl.top * sizeof(int), hipMemcpyHostToDevice, a->stream));
+    ACHK(a, hipMemsetAsync(a->d_next, 0, sizeof(int), a->stream));
+    ACHK(a, hipStreamSynchronize(a->stream));                     // (ctl is on the stack of this function)
+    hipLaunchKernelGGL(wfa_align_kernel, dim3((unsigned)blocks), dim3(TPB), 0, a->stream, a->d_ref, a->plen, a->d_seqs, a->d_off, todo, n_todo, a->d_aln, (size_t)a->plen + 1,
+                       a->d_score, a->d_status, a->d_cells, a->d_pool, a->d_ctl, a->d_stack, a->d_next, a->P);
+    ACHK(a, hipGetLastError());
+    a->passes++;
+    ACHK(a, hipMemcpyAsync(status.data(), a->d_status, (size_t)a->n * sizeof(int), hipMemcpyDeviceToHost, a->stream));
+    ACHK(a, hipStreamSynchronize(a->stream));
+    list.clear();
+    auto look = [&](int i) -> int {
+      if (status[(size_t)i] == ST_OVERFLOW) list.push_back(i);
+      else if (status[(size_t)i] == ST_MAXSCORE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: alignment score above %d, the size of the reference's score table", i, a->P.max_score);
+      else if (status[(size_t)i] == ST_TOOWIDE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: a wavefront wider than the workspace's chunks hold (%zu bytes each)", i, (size_t)4 << a->chunk_log2);
+      else if (status[(size_t)i] != ST_OK) return afail(a, UVAIA_ALIGN_ESTATE, "sequence %d: inconsistent backtrace", i);
+      return 0;
+    };
+    // (the status array holds what the last kernel to run a query left: only the queries of this launch are looked at)
+    if (todo_list.empty()) { for (int i = 0; i < a->n; i++) { const int rc = look(i); if (rc) return rc; } }
+    else for (int i : todo_list) { const int rc = look(i); if (rc) return rc; }
+    if (list.empty()) break;
+    bool grew = false;                                             // queries found the pool empty: a workspace of the library's choosing grows first, ...
+    { const int rc = ensure_pool_memory(a, true, &grew); if (rc) return rc; }
+    if (!grew) {                                                   // ... then fewer queries go in flight
+      if (blocks == 1) return afail(a, UVAIA_ALIGN_ENOMEM, "sequence %d needs more than the whole workspace (%zu bytes) for its wavefronts", list[0], ((size_t)a->n_chunks * 4) << a->chunk_log2);
+      blocks = std::max(1, std::min((int)list.size(), blocks / 4));
+    }
+    todo_list = list;
+    ACHK(a, hipMemcpyAsync(a->d_todo, todo_list.data(), todo_list.size() * sizeof(int), hipMemcpyHostToDevice, a->stream));
+    ACHK(a, hipStreamSynchronize(a->stream));
+    todo = a->d_todo; n_todo = (int)todo_list.size();
+    if (grew) blocks = std::max(1, std::min(std::min(n_todo, a->max_blocks), a->n_chunks / 3));
+  }
   return 0;
 }
 
@@ -634,48 +753,7 @@ int uvaia_align_run(uvaia_aligner *a)
   int rc = ensure_pool_memory(a, false, nullptr); if (rc) return rc;
   ACHK(a, hipMemsetAsync(a->d_cells, 0, sizeof(unsigned long long), a->stream));
   ACHK(a, hipEventRecord(a->ev_a, a->stream));
-  // every block keeps two chunks for the whole launch; the rest of the pool is what the queries in flight share
-  int n_todo = a->n, blocks = std::max(1, std::min(std::min(a->n, a->max_blocks), a->n_chunks / 3));
-  const int *todo = nullptr;
-  std::vector<int> status((size_t)a->n), list;
-  for (;;) {
-    const PoolCtl ctl{0, a->n_chunks - 2 * blocks, a->n_chunks, a->chunk_log2};
-    for (int i = 0; i < ctl.top; i++) a->h_stack[(size_t)i] = 2 * blocks + i;
-    ACHK(a, hipMemcpyAsync(a->d_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice, a->stream));
-    if (ctl.top > 0) ACHK(a, hipMemcpyAsync(a->d_stack, a->h_stack.data(), (size_t)ctl.top * sizeof(int), hipMemcpyHostToDevice, a->stream));
-    ACHK(a, hipMemsetAsync(a->d_next, 0, sizeof(int), a->stream));
-    ACHK(a, hipStreamSynchronize(a->stream));                     // (ctl is on the stack of this function)
-    hipLaunchKernelGGL(wfa_align_kernel, dim3((unsigned)blocks), dim3(TPB), 0, a->stream, a->d_ref, a->plen, a->d_seqs, a->d_off, todo, n_todo, a->d_aln, (size_t)a->plen + 1,
-                       a->d_score, a->d_status, a->d_cells, a->d_pool, a->d_ctl, a->d_stack, a->d_next, a->P);
-    ACHK(a, hipGetLastError());
-    a->passes++;
-    ACHK(a, hipMemcpyAsync(status.data(), a->d_status, (size_t)a->n * sizeof(int), hipMemcpyDeviceToHost, a->stream));
-    ACHK(a, hipStreamSynchronize(a->stream));
-    list.clear();
-    for (int i = 0; i < a->n; i++) {
-      if (status[(size_t)i] == ST_OVERFLOW) list.push_back(i);
-      else if (status[(size_t)i] == ST_MAXSCORE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: alignment score above %d, the size of the reference's score table", i, a->P.max_score);
-      else if (status[(size_t)i] == ST_TOOWIDE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: a wavefront wider than the workspace's chunks hold (%zu bytes each)", i, (size_t)4 << a->chunk_log2);
-      else if (status[(size_t)i] == ST_BACKTRACE) return afail(a, UVAIA_ALIGN_ESTATE, "sequence %d: inconsistent backtrace", i);
-    }
-    if (list.empty()) break;
-    {   // queries found the pool empty: a workspace of the library's choosing grows first, then fewer queries go in flight
-      bool grew = false;
-      rc = ensure_pool_memory(a, true, &grew); if (rc) return rc;
-      if (grew) {
-        ACHK(a, hipMemcpyAsync(a->d_todo, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, a->stream));
-        ACHK(a, hipStreamSynchronize(a->stream));
-        todo = a->d_todo; n_todo = (int)list.size();
-        blocks = std::max(1, std::min(std::min(n_todo, a->max_blocks), a->n_chunks / 3));
-        continue;
-      }
-    }
-    if (blocks == 1) return afail(a, UVAIA_ALIGN_ENOMEM, "sequence %d needs more than the whole workspace (%zu bytes) for its wavefronts", list[0], ((size_t)a->n_chunks * 4) << a->chunk_log2);
-    blocks = std::max(1, std::min((int)list.size(), blocks / 4));
-    ACHK(a, hipMemcpyAsync(a->d_todo, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, a->stream));
-    ACHK(a, hipStreamSynchronize(a->stream));
-    todo = a->d_todo; n_todo = (int)list.size();
-  }
+  rc = run_passes(a); if (rc) return rc;
   ACHK(a, hipEventRecord(a->ev_b, a->stream));
   ACHK(a, hipEventSynchronize(a->ev_b));
   float ms = 0; ACHK(a, hipEventElapsedTime(&ms, a->ev_a, a->ev_b)); a->kernel_ms = ms;

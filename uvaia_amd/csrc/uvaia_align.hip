@@ -221,13 +221,15 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         const int slot_s = lds_s ? (cslot >= d_s ? cslot - d_s : cslot - d_s + RM) : 0, slot_g = lds_g ? (cslot >= d_g ? cslot - d_g : cslot - d_g + RM) : 0;
         const int slot_e = lds_e ? (cislot >= d_e ? cislot - d_e : cislot - d_e + RID) : 0;
         const bool sources_in_lds = (!(hs.flags & 1) || lds_s) && (!(hg.flags & 1) || lds_g) && (!(he.flags & 6) || lds_e);
-        // The step proper, compiled twice.  LDS_ONLY: the usual step -- this wavefront fits in LDS, so do all it reads, and I and D need no
-        // copy in memory: nothing but the history of the backtrace leaves the CU, and none of the bookkeeping of the other kind of step
-        // (positions in the ring chunk, pointers to sources in memory, which of them to wait for) is executed.  Returns true when the
-        // forward pass has to stop (status set).
+        // The step proper, compiled twice.  LDS_ONLY: the usual step -- this wavefront fits in LDS, so do all it reads, all five source
+        // wavefronts exist, and I and D need no copy in memory: nothing but the history of the backtrace leaves the CU, and none of the
+        // bookkeeping of the other kind of step (positions in the ring chunk, pointers to sources in memory, which of them to wait for,
+        // which wavefronts there are at all) is executed.  Returns true when the forward pass has to stop (status set).
+        const bool all_sources = score > 0 && (hs.flags & 1) && (hg.flags & 1) && (he.flags & 6) == 6;
         auto step_body = [&](auto lds_only_tag) -> bool {
         constexpr bool LDS_ONLY = decltype(lds_only_tag)::value;
-        const bool resident = LDS_ONLY || fits;
+        const bool resident = LDS_ONLY || fits, some = LDS_ONLY || score > 0, with_i = LDS_ONLY || has_i, with_d = LDS_ONLY || has_d;
+        auto inside = [&](const Hdr &h, int bit, int k) -> bool { return LDS_ONLY ? (k >= h.lo && k <= h.hi) : in_range(h, bit, k); };
         size_t id_at = 0;
         if (!LDS_ONLY) {
           // the ring chunk keeps the I and D wavefronts of the last e + 1 steps: e + 2 pairs of the widest one must fit (one is lost to the wrap)
@@ -261,8 +263,8 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
           const bool act = k <= hi;
           int m = 0;
           unsigned code = C_MISMATCH;
-          if (score > 0) {
-            const bool in_s = in_range(hs, 0, k), in_gm = in_range(hg, 0, k - 1), in_gp = in_range(hg, 0, k + 1), in_i = in_range(he, 1, k - 1), in_d = in_range(he, 2, k + 1);
+          if (some) {
+            const bool in_s = inside(hs, 0, k), in_gm = inside(hg, 0, k - 1), in_gp = inside(hg, 0, k + 1), in_i = inside(he, 1, k - 1), in_d = inside(he, 2, k + 1);
             int r_s, r_gm, r_gp, r_i, r_d;
             if (all_lds) {     // the usual case: five unconditional LDS reads at clamped positions, the range tests as selects (no branches)
               const int xs = min(max(k - hs.lo_base, 0), WL - 1), xm = min(max(k - 1 - hg.lo_base, 0), WL - 1), xp = min(max(k + 1 - hg.lo_base, 0), WL - 1);
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
             // the five predecessors as the backtrace sees them (a "+ 1" belongs to a fetched value only)
             const int v_sub = in_s ? r_s + 1 : WFA_NULL, v_io = in_gm ? r_gm + 1 : WFA_NULL, v_ie = in_i ? r_i + 1 : WFA_NULL, v_do = r_gp, v_de = r_d;
             m = v_sub;
-            if (has_i) { const int ins = max(r_gm, r_i) + 1; if (act) { if (resident) li[cislot][k - lo] = (uint16_t)(ins + 16); if (id_to_memory) out_i[k - lo] = (uint32_t)ins; } m = max(m, ins); }
-            if (has_d) { const int del = max(r_gp, r_d);     if (act) { if (resident) ld[cislot][k - lo] = (uint16_t)(del + 16); if (id_to_memory) out_d[k - lo] = (uint32_t)del; } m = max(m, del); }
+            if (with_i) { const int ins = max(r_gm, r_i) + 1; if (act) { if (resident) li[cislot][k - lo] = (uint16_t)(ins + 16); if (id_to_memory) out_i[k - lo] = (uint32_t)ins; } m = max(m, ins); }
+            if (with_d) { const int del = max(r_gp, r_d);     if (act) { if (resident) ld[cislot][k - lo] = (uint16_t)(del + 16); if (id_to_memory) out_d[k - lo] = (uint32_t)del; } m = max(m, del); }
             const int bt = max(v_sub, max(max(v_io, v_ie), max(v_do, v_de)));
             code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
             code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         cslot = cslot + 1 == RM ? 0 : cslot + 1; cislot = cislot + 1 == RID ? 0 : cislot + 1;
         return false;
         };
-        if ((fits && sources_in_lds && !id_deep) ? step_body(BoolTag<true>()) : step_body(BoolTag<false>())) break;
+        if ((fits && all_sources && sources_in_lds && !id_deep) ? step_body(BoolTag<true>()) : step_body(BoolTag<false>())) break;
       }
       if (reached) break;
       score += P.g;                                             // scores that are no multiple of gcd(x, o + e, e) have no wavefront (and no header: never looked up)

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
   // in LDS (offset + 16 in 16 bits: the null offset is 6) as long as they are at most WL wide, and the history in memory is written
   // without being waited for.  A step then costs LDS latency plus one round trip for the characters of the extension.
   __shared__ uint16_t lm[RM][WL], li[RID][WL], ld[RID][WL];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
   const int chunk_log2 = ctl->chunk_log2;
   const unsigned chunk_words = 1u << chunk_log2;
   const size_t home_base = (size_t)(2 * blockIdx.x) << chunk_log2, ring_base = (size_t)(2 * blockIdx.x + 1) << chunk_log2;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
   for (;;) {
     if (tid == 0) bc[0] = atomicAdd(next_query, 1);
     __syncthreads();
-    const int qi = bc[0];
+    const int qi = rfl(bc[0]);                                // (read back from LDS: the same in every lane, and the compiler should know)
     if (qi >= n_todo) break;                                  // every wave of every block reaches this: the counter only grows
     const int q = todo ? todo[qi] : qi;
     const uint8_t *text = seqs + seq_off[q];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
           bc[1] = id;
         }
         __syncthreads();
-        const int id = bc[1];
+        const int id = rfl(bc[1]);
         if (id < 0) return false;
         n_own++;
         cur_base = (size_t)id << chunk_log2; cur_used = 0;
@@ -185,24 +185,20 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         if (tid == 0) hdr_page[page] = (uint32_t)(at >> 4);
         __syncthreads();
       }
-      Hdr hs{}, hg{}, he{};
-      bool have = false;
+      // the headers of the three source scores: the same for every lane, kept in scalar registers (a score below zero has none; where
+      // the arrays lie in memory -- off16, w, id16 -- is looked up only by a step that has to read a source from there)
+      auto load = [&](int s) -> Hdr {
+        Hdr h{};
+        if (s >= 0) { const int *r = ring[s & (RING - 1)]; h.lo = rfl(r[0]); h.hi = rfl(r[1]); h.lo_base = rfl(r[2]); h.flags = rfl(r[3]); h.res = rfl(r[7]); }
+        return h;
+      };
+      const Hdr hs = load(score - P.x), hg = load(score - P.oe), he = load(score - P.e);
+      const bool n_sub = !(hs.flags & 1), n_gap = !(hg.flags & 1), n_i = !(he.flags & 2), n_d = !(he.flags & 4);
+      const bool have = score == 0 || !(n_sub && n_gap && n_i && n_d);
       int lo = 0, hi = 0;
-      if (score == 0) have = true;
-      else {
-        auto load = [&](int s, Hdr &h) {
-          if (s < 0) { h.flags = 0; return; }
-          const int *r = ring[s & (RING - 1)];            // the same for every lane: kept in scalar registers
-          // (where the arrays lie in memory -- off16, w, id16 -- is looked up only by a step that has to read a source from there)
-          h.lo = rfl(r[0]); h.hi = rfl(r[1]); h.lo_base = rfl(r[2]); h.flags = rfl(r[3]); h.res = rfl(r[7]);
-        };
-        load(score - P.x, hs); load(score - P.oe, hg); load(score - P.e, he);
-        const bool n_sub = !(hs.flags & 1), n_gap = !(hg.flags & 1), n_i = !(he.flags & 2), n_d = !(he.flags & 4);
-        if (!(n_sub && n_gap && n_i && n_d)) {
-          have = true;
-          lo = min(min(n_sub ? 1 : hs.lo, n_gap ? 1 : hg.lo), min(n_i ? 1 : he.lo, n_d ? 1 : he.lo)) - 1;
-          hi = max(max(n_sub ? -1 : hs.hi, n_gap ? -1 : hg.hi), max(n_i ? -1 : he.hi, n_d ? -1 : he.hi)) + 1;
-        }
+      if (score > 0 && have) {
+        lo = min(min(n_sub ? 1 : hs.lo, n_gap ? 1 : hg.lo), min(n_i ? 1 : he.lo, n_d ? 1 : he.lo)) - 1;
+        hi = max(max(n_sub ? -1 : hs.hi, n_gap ? -1 : hg.hi), max(n_i ? -1 : he.hi, n_d ? -1 : he.hi)) + 1;
       }
       int *hdr_out = reinterpret_cast<int *>(pool + ((size_t)hdr_page[score / HDR_PAGE_SCORES] << 4)) + (size_t)(score & (HDR_PAGE_SCORES - 1)) * HDR_INTS;
       int *ring_out = ring[score & (RING - 1)];
@@ -356,6 +352,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         min_distance = wsync[step & 1][0][0]; reached = wsync[step & 1][0][1] != 0;
 #pragma unroll
         for (int u = 1; u < NW; u++) { min_distance = min(min_distance, wsync[step & 1][u][0]); reached = reached || wsync[step & 1][u][1] != 0; }
+        min_distance = rfl(min_distance); reached = rfl(reached ? 1 : 0) != 0;     // uniform: the loop over the scores is a scalar loop
         const int par = step & 1;
         step++;
         // adaptive reduction (paper section 2.4): trim both ends of a long wavefront, never across the end cell's diagonal.
@@ -505,6 +502,27 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
   if (tid == 0 && cells_total) atomicAdd(cells_out, cells_total);
 }
 
+// What a query is going to cost, roughly: every site that is no A, C, G or T is a mismatch against the reference (4 each, and N runs
+// are what makes scores of tens of thousands), every character of length difference a gap extension.  The blocks are persistent and
+// take the next query when they finish one, so the last queries to start decide how long the launch's tail is: the dearer half of
+// the pool is started first, in the order it came (all of the dearest at once would also want all of the workspace at once), then
+// the cheaper half in descending order of the estimate.  One block per query.
+__global__ __launch_bounds__(256) void expected_cost_kernel(const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off, int plen, int n, int *__restrict__ cost)
+{
+  __shared__ int part[4];
+  const int q = blockIdx.x;
+  if (q >= n) return;
+  const uint8_t *t = seqs + seq_off[q];
+  const int tlen = (int)(seq_off[q + 1] - seq_off[q]);
+  int c = 0;
+  for (int i = threadIdx.x; i < tlen; i += 256) { const uint8_t ch = t[i] & 0xDF; c += !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cost[q] = 4 * (part[0] + part[1] + part[2] + part[3]) + 2 * abs(tlen - plen);
+}
+
 thread_local std::string g_align_open_error;
 
 }  // namespace
@@ -516,7 +534,7 @@ struct uvaia_aligner {
   WfaParams P{};
   uint8_t *d_ref = nullptr, *d_seqs = nullptr, *d_aln = nullptr;
   long long *d_off = nullptr;
-  int *d_score = nullptr, *d_status = nullptr, *d_next = nullptr, *d_todo = nullptr;
+  int *d_score = nullptr, *d_status = nullptr, *d_next = nullptr, *d_todo = nullptr, *d_order = nullptr;   // d_order: the pool's queries, the dearest first
   unsigned long long *d_cells = nullptr;
   uint32_t *d_pool = nullptr;               // wavefront memory: n_chunks chunks of 2^chunk_log2 words
   PoolCtl *d_ctl = nullptr; int *d_stack = nullptr;
@@ -554,14 +572,15 @@ int ensure_pool(uvaia_aligner *a, size_t bytes, int n)
     ACHK(a, hipMalloc(&a->d_seqs, cap)); a->seqs_cap = cap;
   }
   if ((size_t)n > a->n_cap) {
-    hipFree(a->d_off); hipFree(a->d_aln); hipFree(a->d_score); hipFree(a->d_status); hipFree(a->d_todo);
-    a->d_off = nullptr; a->d_aln = nullptr; a->d_score = a->d_status = a->d_todo = nullptr; a->n_cap = 0;
+    hipFree(a->d_off); hipFree(a->d_aln); hipFree(a->d_score); hipFree(a->d_status); hipFree(a->d_todo); hipFree(a->d_order);
+    a->d_off = nullptr; a->d_aln = nullptr; a->d_score = a->d_status = a->d_todo = a->d_order = nullptr; a->n_cap = 0;
     const size_t cap = std::max<size_t>((size_t)n * 5 / 4, 256);
     ACHK(a, hipMalloc(&a->d_off, (cap + 1) * sizeof(long long)));
     ACHK(a, hipMalloc(&a->d_aln, cap * ((size_t)a->plen + 1)));
     ACHK(a, hipMalloc(&a->d_score, cap * sizeof(int)));
     ACHK(a, hipMalloc(&a->d_status, cap * sizeof(int)));
     ACHK(a, hipMalloc(&a->d_todo, cap * sizeof(int)));
+    ACHK(a, hipMalloc(&a->d_order, cap * sizeof(int)));
     a->n_cap = cap;
   }
   return 0;
@@ -603,7 +622,7 @@ int run_passes(uvaia_aligner *a)
 {
   int n_todo = a->n;
   int blocks = std::max(1, std::min(std::min(n_todo, a->max_blocks), a->n_chunks / 3));
-  const int *todo = nullptr;
+  const int *todo = a->d_order;                                       // the first launch: every query of the pool, the dearest first
   std::vector<int> status((size_t)a->n), list, todo_list;             // todo_list empty: all queries of the pool
   for (;;) {
     // every block keeps two chunks for the whole launch; the rest of the pool is what the queries in flight share
@@ -666,7 +685,7 @@ void uvaia_align_close(uvaia_aligner *a)
   hipSetDevice(a->device);
   if (a->stream) hipStreamSynchronize(a->stream);
   hipFree(a->d_ref); hipFree(a->d_seqs); hipFree(a->d_aln); hipFree(a->d_off); hipFree(a->d_score); hipFree(a->d_status); hipFree(a->d_next);
-  hipFree(a->d_todo); hipFree(a->d_cells); hipFree(a->d_pool); hipFree(a->d_ctl); hipFree(a->d_stack);
+  hipFree(a->d_todo); hipFree(a->d_order); hipFree(a->d_cells); hipFree(a->d_pool); hipFree(a->d_ctl); hipFree(a->d_stack);
   if (a->ev_a) hipEventDestroy(a->ev_a);
   if (a->ev_b) hipEventDestroy(a->ev_b);
   if (a->stream) hipStreamDestroy(a->stream);
@@ -730,6 +749,17 @@ int uvaia_align_load_block(uvaia_aligner *a, const char *bytes, const int64_t *o
   ACHK(a, hipStreamSynchronize(a->stream));
   if (total) ACHK(a, hipMemcpyAsync(a->d_seqs, bytes + offsets[0], total, hipMemcpyHostToDevice, a->stream));
   ACHK(a, hipMemcpyAsync(a->d_off, a->h_off.data(), ((size_t)n + 1) * sizeof(long long), hipMemcpyHostToDevice, a->stream));
+  {   // the order the queries are started in (d_status is free until the run: it takes the estimates)
+    hipLaunchKernelGGL(expected_cost_kernel, dim3((unsigned)n), dim3(256), 0, a->stream, a->d_seqs, a->d_off, a->plen, n, a->d_status);
+    ACHK(a, hipGetLastError());
+    std::vector<int> cost((size_t)n), order((size_t)n);
+    ACHK(a, hipMemcpyAsync(cost.data(), a->d_status, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, a->stream));
+    ACHK(a, hipStreamSynchronize(a->stream));
+    for (int i = 0; i < n; i++) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    std::sort(order.begin(), order.begin() + n / 2);
+    ACHK(a, hipMemcpyAsync(a->d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, a->stream));
+  }
   ACHK(a, hipStreamSynchronize(a->stream));
   a->n = n;
   return 0;

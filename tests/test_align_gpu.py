@@ -57,6 +57,20 @@ def test_sars_cov_2_shaped_queries_equal_oracle():
     assert score.max() > 600                                   # N runs cost 4 per site: the reduction is in play
 
 
+def test_results_do_not_depend_on_the_order_of_the_pool():
+    """the aligner starts the queries of a pool by expected cost (the dearer half first, the cheaper half in descending order):
+    every query's row and score are its own, whatever came before it and wherever it stands in the pool"""
+    ref = F.random_acgt(4000, 21)
+    seqs = F.unaligned_queries(ref, 120, 22, n_runs=(40, 30, 300)) + [b"N" * 3000, ref, ref[:100], b"N" * 10 + ref[10:]]
+    with align.Aligner(ref) as al:
+        s1, r1 = al.align(seqs)
+        s2, r2 = al.align(seqs[::-1])
+        s3, r3 = al.align(seqs[:7])
+    assert np.array_equal(s1, s2[::-1]) and all(a.tobytes() == b.tobytes() for a, b in zip(r1, r2[::-1]))
+    assert np.array_equal(s1[:7], s3) and all(a.tobytes() == b.tobytes() for a, b in zip(r1[:7], r3))
+    assert len(set(int(x) for x in s1)) > 20                    # scores differ widely: the start order is not the pool's
+
+
 def test_resident_pool_and_repeat_runs_agree():
     ref = F.random_acgt(5000, 9)
     seqs = F.unaligned_queries(ref, 300, 10, n_runs=(50, 40, 200))

@@ -223,176 +223,176 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
         // which wavefronts there are at all) is executed.  Returns true when the forward pass has to stop (status set).
         const bool all_sources = score > 0 && (hs.flags & 1) && (hg.flags & 1) && (he.flags & 6) == 6;
         auto step_body = [&](auto lds_only_tag) -> bool {
-        constexpr bool LDS_ONLY = decltype(lds_only_tag)::value;
-        const bool resident = LDS_ONLY || fits, some = LDS_ONLY || score > 0, with_i = LDS_ONLY || has_i, with_d = LDS_ONLY || has_d;
-        auto inside = [&](const Hdr &h, int bit, int k) -> bool { return LDS_ONLY ? (k >= h.lo && k <= h.hi) : in_range(h, bit, k); };
-        size_t id_at = 0;
-        if (!LDS_ONLY) {
-          // the ring chunk keeps the I and D wavefronts of the last e + 1 steps: e + 2 pairs of the widest one must fit (one is lost to the wrap)
-          widest16 = max(widest16, (unsigned)w16);
-          if ((unsigned long long)(P.e + 2) * 2ull * widest16 > chunk_words || hist_words > chunk_words) { status = ST_TOOWIDE; return true; }
-          if (ring_pos + 2u * (unsigned)w16 > chunk_words) ring_pos = 0;
-          id_at = ring_base + ring_pos;
-          ring_pos += 2u * (unsigned)w16;
-        }
-        size_t m_at = 0;
-        if (!take(hist_words, m_at)) { status = ST_OVERFLOW; return true; }
-        cells += (unsigned)w;
-        const bool id_to_memory = !LDS_ONLY && (!resident || id_deep);      // (more existing scores between s - e and s than LDS slots: keep a copy)
-        const bool all_lds = LDS_ONLY || sources_in_lds;
-        // a source that left LDS is read from memory, where its step wrote it without waiting: make those stores complete first
-        if (!LDS_ONLY && (((hs.flags & 1) && hs.res && !lds_s) || ((hg.flags & 1) && hg.res && !lds_g) || ((he.flags & 6) && he.res && !lds_e))) __syncthreads();
-        uint32_t *out_m = pool + m_at, *out_i = pool + id_at, *out_d = out_i + w16;
-        uint8_t *out_c = reinterpret_cast<uint8_t *>(out_m + w16);
-        // sources in memory (a step that is not all_lds): M of score - x, M of score - o - e, I and D of score - e
-        auto mem_m = [&](int s_, const Hdr &h_) -> const uint32_t * { return pool + ((size_t)(uint32_t)ring[s_ & (RING - 1)][4] << 4) - h_.lo_base; };
-        auto mem_i = [&](int s_, const Hdr &h_) -> const uint32_t * { return pool + ((size_t)(uint32_t)ring[s_ & (RING - 1)][6] << 4) - h_.lo_base; };
-        int min_distance = max(plen, tlen);
-        bool hit_end = false;
-        // A cell in two halves.  front: its offset before the extension (five offsets from LDS, I and D stored) and the request for the
-        // first eight characters of either sequence; back: the extension and the stores.  A wave takes its diagonals WFA_GROUP x 64 at
-        // a time, all fronts before the first back: one LDS and one memory round trip per group instead of one per 64 diagonals.
-        struct Cell { int k, m; unsigned code; bool act, go; unsigned long long x, y; };
-        auto front = [&](int k0) -> Cell {
-          Cell c;
-          const int k = k0 + lane;
-          const bool act = k <= hi;
-          int m = 0;
-          unsigned code = C_MISMATCH;
-          if (some) {
-            const bool in_s = inside(hs, 0, k), in_gm = inside(hg, 0, k - 1), in_gp = inside(hg, 0, k + 1), in_i = inside(he, 1, k - 1), in_d = inside(he, 2, k + 1);
-            int r_s, r_gm, r_gp, r_i, r_d;
-            if (all_lds) {     // the usual case: five unconditional LDS reads at clamped positions, the range tests as selects (no branches)
-              const int xs = min(max(k - hs.lo_base, 0), WL - 1), xm = min(max(k - 1 - hg.lo_base, 0), WL - 1), xp = min(max(k + 1 - hg.lo_base, 0), WL - 1);
-              const int xi = min(max(k - 1 - he.lo_base, 0), WL - 1), xd = min(max(k + 1 - he.lo_base, 0), WL - 1);
-              const int a_s = (int)lm[slot_s][xs] - 16, a_m = (int)lm[slot_g][xm] - 16, a_p = (int)lm[slot_g][xp] - 16, a_i = (int)li[slot_e][xi] - 16, a_d = (int)ld[slot_e][xd] - 16;
-              r_s = in_s ? a_s : WFA_NULL; r_gm = in_gm ? a_m : WFA_NULL; r_gp = in_gp ? a_p : WFA_NULL; r_i = in_i ? a_i : WFA_NULL; r_d = in_d ? a_d : WFA_NULL;
-            } else {
-              const uint32_t *ms = (hs.flags & 1) && !lds_s ? mem_m(score - P.x, hs) : pool, *mg = (hg.flags & 1) && !lds_g ? mem_m(score - P.oe, hg) : pool;
-              const uint32_t *ie = (he.flags & 6) && !lds_e ? mem_i(score - P.e, he) : pool, *de = ie + ((he.flags & 6) && !lds_e ? w16_of(ring[(score - P.e) & (RING - 1)][5]) : 0);
-              r_s  = in_s  ? (lds_s ? (int)lm[slot_s][k - hs.lo_base] - 16     : (int)ms[k])     : WFA_NULL;
-              r_gm = in_gm ? (lds_g ? (int)lm[slot_g][k - 1 - hg.lo_base] - 16 : (int)mg[k - 1]) : WFA_NULL;
-              r_gp = in_gp ? (lds_g ? (int)lm[slot_g][k + 1 - hg.lo_base] - 16 : (int)mg[k + 1]) : WFA_NULL;
-              r_i  = in_i  ? (lds_e ? (int)li[slot_e][k - 1 - he.lo_base] - 16 : (int)ie[k - 1]) : WFA_NULL;
-              r_d  = in_d  ? (lds_e ? (int)ld[slot_e][k + 1 - he.lo_base] - 16 : (int)de[k + 1]) : WFA_NULL;
-            }
-            // the five predecessors as the backtrace sees them (a "+ 1" belongs to a fetched value only)
-            const int v_sub = in_s ? r_s + 1 : WFA_NULL, v_io = in_gm ? r_gm + 1 : WFA_NULL, v_ie = in_i ? r_i + 1 : WFA_NULL, v_do = r_gp, v_de = r_d;
-            m = v_sub;
-            if (with_i) { const int ins = max(r_gm, r_i) + 1; if (act) { if (resident) li[cislot][k - lo] = (uint16_t)(ins + 16); if (id_to_memory) out_i[k - lo] = (uint32_t)ins; } m = max(m, ins); }
-            if (with_d) { const int del = max(r_gp, r_d);     if (act) { if (resident) ld[cislot][k - lo] = (uint16_t)(del + 16); if (id_to_memory) out_d[k - lo] = (uint32_t)del; } m = max(m, del); }
-            const int bt = max(v_sub, max(max(v_io, v_ie), max(v_do, v_de)));
-            code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
-            code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
+          constexpr bool LDS_ONLY = decltype(lds_only_tag)::value;
+          const bool resident = LDS_ONLY || fits, some = LDS_ONLY || score > 0, with_i = LDS_ONLY || has_i, with_d = LDS_ONLY || has_d;
+          auto inside = [&](const Hdr &h, int bit, int k) -> bool { return LDS_ONLY ? (k >= h.lo && k <= h.hi) : in_range(h, bit, k); };
+          size_t id_at = 0;
+          if (!LDS_ONLY) {
+            // the ring chunk keeps the I and D wavefronts of the last e + 1 steps: e + 2 pairs of the widest one must fit (one is lost to the wrap)
+            widest16 = max(widest16, (unsigned)w16);
+            if ((unsigned long long)(P.e + 2) * 2ull * widest16 > chunk_words || hist_words > chunk_words) { status = ST_TOOWIDE; return true; }
+            if (ring_pos + 2u * (unsigned)w16 > chunk_words) ring_pos = 0;
+            id_at = ring_base + ring_pos;
+            ring_pos += 2u * (unsigned)w16;
           }
-          // exact extension along the diagonal (paper algorithm 2): eight characters per lane in one round trip (the loads may run up to
-          // seven bytes past a sequence: both buffers are padded) ...
-          const int v = m - k, h = m;
-          c.k = k; c.m = m; c.code = code; c.act = act;
-          c.go = act && (unsigned)h < (unsigned)tlen && (unsigned)v < (unsigned)plen;
-          c.x = 0ull; c.y = 0ull;
-          if (c.go) { __builtin_memcpy(&c.x, ref + v, 8); __builtin_memcpy(&c.y, text + h, 8); }
-          return c;
-        };
-        auto back = [&](const Cell &c, int k0) {
-          const int k = c.k;
-          int m = c.m, v = m - k, h = m;
-          bool go = c.go;
-          {   // (no branch around this: a wait for the characters that a path can skip makes the next cells wait for this cell's stores)
-            const unsigned long long d = c.x ^ c.y;
-            const int nmat = go ? min(d ? (int)(__builtin_ctzll(d) >> 3) : 8, min(plen - v, tlen - h)) : 0;
-            v += nmat; h += nmat; m += nmat;
-            go = go && nmat == 8 && v < plen && h < tlen;
-          }
-          // ... longer runs by the whole wave, 1 024 characters per round trip
-          unsigned long long more = __ballot(go);
-          while (more) {
-            const int j = __builtin_ctzll(more);
-            more &= more - 1;
-            const int vj = __shfl(v, j), hj = __shfl(h, j);
-            int ext = 0;
-            for (;;) {
-              unsigned long long part[2];
-              int nm_[2];
-#pragma unroll
-              for (int u = 0; u < 2; u++) {
-                const int pv = vj + ext + (u * 64 + lane) * 8, ph = hj + ext + (u * 64 + lane) * 8;
-                nm_[u] = (pv < plen && ph < tlen) ? min(matching_prefix8(ref + pv, text + ph), min(plen - pv, tlen - ph)) : 0;
-                part[u] = __ballot(nm_[u] < 8);
+          size_t m_at = 0;
+          if (!take(hist_words, m_at)) { status = ST_OVERFLOW; return true; }
+          cells += (unsigned)w;
+          const bool id_to_memory = !LDS_ONLY && (!resident || id_deep);      // (more existing scores between s - e and s than LDS slots: keep a copy)
+          const bool all_lds = LDS_ONLY || sources_in_lds;
+          // a source that left LDS is read from memory, where its step wrote it without waiting: make those stores complete first
+          if (!LDS_ONLY && (((hs.flags & 1) && hs.res && !lds_s) || ((hg.flags & 1) && hg.res && !lds_g) || ((he.flags & 6) && he.res && !lds_e))) __syncthreads();
+          uint32_t *out_m = pool + m_at, *out_i = pool + id_at, *out_d = out_i + w16;
+          uint8_t *out_c = reinterpret_cast<uint8_t *>(out_m + w16);
+          // sources in memory (a step that is not all_lds): M of score - x, M of score - o - e, I and D of score - e
+          auto mem_m = [&](int s_, const Hdr &h_) -> const uint32_t * { return pool + ((size_t)(uint32_t)ring[s_ & (RING - 1)][4] << 4) - h_.lo_base; };
+          auto mem_i = [&](int s_, const Hdr &h_) -> const uint32_t * { return pool + ((size_t)(uint32_t)ring[s_ & (RING - 1)][6] << 4) - h_.lo_base; };
+          int min_distance = max(plen, tlen);
+          bool hit_end = false;
+          // A cell in two halves.  front: its offset before the extension (five offsets from LDS, I and D stored) and the request for the
+          // first eight characters of either sequence; back: the extension and the stores.  A wave takes its diagonals WFA_GROUP x 64 at
+          // a time, all fronts before the first back: one LDS and one memory round trip per group instead of one per 64 diagonals.
+          struct Cell { int k, m; unsigned code; bool act, go; unsigned long long x, y; };
+          auto front = [&](int k0) -> Cell {
+            Cell c;
+            const int k = k0 + lane;
+            const bool act = k <= hi;
+            int m = 0;
+            unsigned code = C_MISMATCH;
+            if (some) {
+              const bool in_s = inside(hs, 0, k), in_gm = inside(hg, 0, k - 1), in_gp = inside(hg, 0, k + 1), in_i = inside(he, 1, k - 1), in_d = inside(he, 2, k + 1);
+              int r_s, r_gm, r_gp, r_i, r_d;
+              if (all_lds) {     // the usual case: five unconditional LDS reads at clamped positions, the range tests as selects (no branches)
+                const int xs = min(max(k - hs.lo_base, 0), WL - 1), xm = min(max(k - 1 - hg.lo_base, 0), WL - 1), xp = min(max(k + 1 - hg.lo_base, 0), WL - 1);
+                const int xi = min(max(k - 1 - he.lo_base, 0), WL - 1), xd = min(max(k + 1 - he.lo_base, 0), WL - 1);
+                const int a_s = (int)lm[slot_s][xs] - 16, a_m = (int)lm[slot_g][xm] - 16, a_p = (int)lm[slot_g][xp] - 16, a_i = (int)li[slot_e][xi] - 16, a_d = (int)ld[slot_e][xd] - 16;
+                r_s = in_s ? a_s : WFA_NULL; r_gm = in_gm ? a_m : WFA_NULL; r_gp = in_gp ? a_p : WFA_NULL; r_i = in_i ? a_i : WFA_NULL; r_d = in_d ? a_d : WFA_NULL;
+              } else {
+                const uint32_t *ms = (hs.flags & 1) && !lds_s ? mem_m(score - P.x, hs) : pool, *mg = (hg.flags & 1) && !lds_g ? mem_m(score - P.oe, hg) : pool;
+                const uint32_t *ie = (he.flags & 6) && !lds_e ? mem_i(score - P.e, he) : pool, *de = ie + ((he.flags & 6) && !lds_e ? w16_of(ring[(score - P.e) & (RING - 1)][5]) : 0);
+                r_s  = in_s  ? (lds_s ? (int)lm[slot_s][k - hs.lo_base] - 16     : (int)ms[k])     : WFA_NULL;
+                r_gm = in_gm ? (lds_g ? (int)lm[slot_g][k - 1 - hg.lo_base] - 16 : (int)mg[k - 1]) : WFA_NULL;
+                r_gp = in_gp ? (lds_g ? (int)lm[slot_g][k + 1 - hg.lo_base] - 16 : (int)mg[k + 1]) : WFA_NULL;
+                r_i  = in_i  ? (lds_e ? (int)li[slot_e][k - 1 - he.lo_base] - 16 : (int)ie[k - 1]) : WFA_NULL;
+                r_d  = in_d  ? (lds_e ? (int)ld[slot_e][k + 1 - he.lo_base] - 16 : (int)de[k + 1]) : WFA_NULL;
               }
-              if (part[0]) { const int l = __builtin_ctzll(part[0]); ext += 8 * l + __shfl(nm_[0], l); break; }
-              if (part[1]) { const int l = __builtin_ctzll(part[1]); ext += 512 + 8 * l + __shfl(nm_[1], l); break; }
-              ext += 1024;
+              // the five predecessors as the backtrace sees them (a "+ 1" belongs to a fetched value only)
+              const int v_sub = in_s ? r_s + 1 : WFA_NULL, v_io = in_gm ? r_gm + 1 : WFA_NULL, v_ie = in_i ? r_i + 1 : WFA_NULL, v_do = r_gp, v_de = r_d;
+              m = v_sub;
+              if (with_i) { const int ins = max(r_gm, r_i) + 1; if (act) { if (resident) li[cislot][k - lo] = (uint16_t)(ins + 16); if (id_to_memory) out_i[k - lo] = (uint32_t)ins; } m = max(m, ins); }
+              if (with_d) { const int del = max(r_gp, r_d);     if (act) { if (resident) ld[cislot][k - lo] = (uint16_t)(del + 16); if (id_to_memory) out_d[k - lo] = (uint32_t)del; } m = max(m, del); }
+              const int bt = max(v_sub, max(max(v_io, v_ie), max(v_do, v_de)));
+              code = bt == v_de ? C_DEL_EXT : bt == v_do ? C_DEL_OPEN : bt == v_ie ? C_INS_EXT : bt == v_io ? C_INS_OPEN : C_MISMATCH;   // the backtrace's tie order
+              code |= (v_ie >= v_io ? C_I_EXT : 0) | (v_de >= v_do ? C_D_EXT : 0);
             }
-            if (lane == j) m += ext;
+            // exact extension along the diagonal (paper algorithm 2): eight characters per lane in one round trip (the loads may run up to
+            // seven bytes past a sequence: both buffers are padded) ...
+            const int v = m - k, h = m;
+            c.k = k; c.m = m; c.code = code; c.act = act;
+            c.go = act && (unsigned)h < (unsigned)tlen && (unsigned)v < (unsigned)plen;
+            c.x = 0ull; c.y = 0ull;
+            if (c.go) { __builtin_memcpy(&c.x, ref + v, 8); __builtin_memcpy(&c.y, text + h, 8); }
+            return c;
+          };
+          auto back = [&](const Cell &c, int k0) {
+            const int k = c.k;
+            int m = c.m, v = m - k, h = m;
+            bool go = c.go;
+            {   // (no branch around this: a wait for the characters that a path can skip makes the next cells wait for this cell's stores)
+              const unsigned long long d = c.x ^ c.y;
+              const int nmat = go ? min(d ? (int)(__builtin_ctzll(d) >> 3) : 8, min(plen - v, tlen - h)) : 0;
+              v += nmat; h += nmat; m += nmat;
+              go = go && nmat == 8 && v < plen && h < tlen;
+            }
+            // ... longer runs by the whole wave, 1 024 characters per round trip
+            unsigned long long more = __ballot(go);
+            while (more) {
+              const int j = __builtin_ctzll(more);
+              more &= more - 1;
+              const int vj = __shfl(v, j), hj = __shfl(h, j);
+              int ext = 0;
+              for (;;) {
+                unsigned long long part[2];
+                int nm_[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                  const int pv = vj + ext + (u * 64 + lane) * 8, ph = hj + ext + (u * 64 + lane) * 8;
+                  nm_[u] = (pv < plen && ph < tlen) ? min(matching_prefix8(ref + pv, text + ph), min(plen - pv, tlen - ph)) : 0;
+                  part[u] = __ballot(nm_[u] < 8);
+                }
+                if (part[0]) { const int l = __builtin_ctzll(part[0]); ext += 8 * l + __shfl(nm_[0], l); break; }
+                if (part[1]) { const int l = __builtin_ctzll(part[1]); ext += 512 + 8 * l + __shfl(nm_[1], l); break; }
+                ext += 1024;
+              }
+              if (lane == j) m += ext;
+            }
+            const int dk_ = c.act ? dist_to_end(plen, tlen, m, k) : 0x7fffffff;
+            if (k0 == lo) dend[step & 1][0][lane] = dk_;
+            if (k0 + 64 > hi) dend[step & 1][1][lane] = dk_;
+            if (c.act) {
+              if (resident) lm[cslot][k - lo] = (uint16_t)(m + 16);
+              out_m[k - lo] = (uint32_t)m;
+              out_c[k - lo] = (uint8_t)c.code;
+              min_distance = min(min_distance, dk_);
+              if (k == alignment_k && m >= tlen) hit_end = true;
+            }
+          };
+          for (int k0 = lo + 64 * wave; k0 <= hi; k0 += WFA_GROUP * TPB) {
+            Cell c[WFA_GROUP];
+#pragma unroll
+            for (int g = 0; g < WFA_GROUP; g++) if (k0 + g * TPB <= hi) c[g] = front(k0 + g * TPB);
+            __builtin_amdgcn_sched_barrier(0);                   // (the scheduler would pair every front with its back again)
+#pragma unroll
+            for (int g = 0; g < WFA_GROUP; g++) if (k0 + g * TPB <= hi) back(c[g], k0 + g * TPB);
           }
-          const int dk_ = c.act ? dist_to_end(plen, tlen, m, k) : 0x7fffffff;
-          if (k0 == lo) dend[step & 1][0][lane] = dk_;
-          if (k0 + 64 > hi) dend[step & 1][1][lane] = dk_;
-          if (c.act) {
-            if (resident) lm[cslot][k - lo] = (uint16_t)(m + 16);
-            out_m[k - lo] = (uint32_t)m;
-            out_c[k - lo] = (uint8_t)c.code;
-            min_distance = min(min_distance, dk_);
-            if (k == alignment_k && m >= tlen) hit_end = true;
-          }
-        };
-        for (int k0 = lo + 64 * wave; k0 <= hi; k0 += WFA_GROUP * TPB) {
-          Cell c[WFA_GROUP];
+          min_distance = wave_min_dpp(min_distance);
+          const bool wave_hit = __any(hit_end);
+          if (lane == 0) { wsync[step & 1][wave][0] = min_distance; wsync[step & 1][wave][1] = wave_hit ? 1 : 0; }
+          if (resident) lds_barrier(); else __syncthreads();      // the one barrier of a step: offsets stored by other waves are read from here on
+          min_distance = wsync[step & 1][0][0]; reached = wsync[step & 1][0][1] != 0;
 #pragma unroll
-          for (int g = 0; g < WFA_GROUP; g++) if (k0 + g * TPB <= hi) c[g] = front(k0 + g * TPB);
-          __builtin_amdgcn_sched_barrier(0);                   // (the scheduler would pair every front with its back again)
-#pragma unroll
-          for (int g = 0; g < WFA_GROUP; g++) if (k0 + g * TPB <= hi) back(c[g], k0 + g * TPB);
-        }
-        min_distance = wave_min_dpp(min_distance);
-        const bool wave_hit = __any(hit_end);
-        if (lane == 0) { wsync[step & 1][wave][0] = min_distance; wsync[step & 1][wave][1] = wave_hit ? 1 : 0; }
-        if (resident) lds_barrier(); else __syncthreads();      // the one barrier of a step: offsets stored by other waves are read from here on
-        min_distance = wsync[step & 1][0][0]; reached = wsync[step & 1][0][1] != 0;
-#pragma unroll
-        for (int u = 1; u < NW; u++) { min_distance = min(min_distance, wsync[step & 1][u][0]); reached = reached || wsync[step & 1][u][1] != 0; }
-        min_distance = rfl(min_distance); reached = rfl(reached ? 1 : 0) != 0;     // uniform: the loop over the scores is a scalar loop
-        const int par = step & 1;
-        step++;
-        // adaptive reduction (paper section 2.4): trim both ends of a long wavefront, never across the end cell's diagonal.
-        // Every wave computes the same limits for itself, as a rule from the two ends' distances in LDS.
-        int rlo = lo, rhi = hi;
-        if (P.min_wf_len > 0 && w >= P.min_wf_len) {
-          const int top_limit = min(alignment_k - 1, hi);
-          if (lo < top_limit) {
-            rlo = top_limit;
-            const unsigned long long b0 = __ballot(lo + lane < top_limit && dend[par][0][lane] - min_distance <= P.max_dist_thr);
-            if (b0) rlo = lo + __builtin_ctzll(b0);
-            else for (int k0 = lo + 64; k0 < top_limit; k0 += 64) {
-              const int k = k0 + lane;
-              const bool keep = k < top_limit && dist_to_end(plen, tlen, resident ? (int)lm[cslot][k - lo] - 16 : (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
-              const unsigned long long b = __ballot(keep);
-              if (b) { rlo = k0 + __builtin_ctzll(b); break; }
+          for (int u = 1; u < NW; u++) { min_distance = min(min_distance, wsync[step & 1][u][0]); reached = reached || wsync[step & 1][u][1] != 0; }
+          min_distance = rfl(min_distance); reached = rfl(reached ? 1 : 0) != 0;     // uniform: the loop over the scores is a scalar loop
+          const int par = step & 1;
+          step++;
+          // adaptive reduction (paper section 2.4): trim both ends of a long wavefront, never across the end cell's diagonal.
+          // Every wave computes the same limits for itself, as a rule from the two ends' distances in LDS.
+          int rlo = lo, rhi = hi;
+          if (P.min_wf_len > 0 && w >= P.min_wf_len) {
+            const int top_limit = min(alignment_k - 1, hi);
+            if (lo < top_limit) {
+              rlo = top_limit;
+              const unsigned long long b0 = __ballot(lo + lane < top_limit && dend[par][0][lane] - min_distance <= P.max_dist_thr);
+              if (b0) rlo = lo + __builtin_ctzll(b0);
+              else for (int k0 = lo + 64; k0 < top_limit; k0 += 64) {
+                const int k = k0 + lane;
+                const bool keep = k < top_limit && dist_to_end(plen, tlen, resident ? (int)lm[cslot][k - lo] - 16 : (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
+                const unsigned long long b = __ballot(keep);
+                if (b) { rlo = k0 + __builtin_ctzll(b); break; }
+              }
+            }
+            const int bottom_limit = max(alignment_k + 1, rlo);
+            if (hi > bottom_limit) {
+              rhi = bottom_limit;
+              const int kh = lo + ((hi - lo) / 64) * 64;                  // first diagonal of the chunk that holds hi
+              const unsigned long long b0 = __ballot(kh + lane <= hi && kh + lane > bottom_limit && dend[par][1][lane] - min_distance <= P.max_dist_thr);
+              if (b0) rhi = kh + 63 - __builtin_clzll(b0);
+              else for (int k0 = kh - 1; k0 > bottom_limit; k0 -= 64) {
+                const int k = k0 - lane;
+                const bool keep = k > bottom_limit && dist_to_end(plen, tlen, resident ? (int)lm[cslot][k - lo] - 16 : (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
+                const unsigned long long b = __ballot(keep);
+                if (b) { rhi = k0 - __builtin_ctzll(b); break; }
+              }
             }
           }
-          const int bottom_limit = max(alignment_k + 1, rlo);
-          if (hi > bottom_limit) {
-            rhi = bottom_limit;
-            const int kh = lo + ((hi - lo) / 64) * 64;                  // first diagonal of the chunk that holds hi
-            const unsigned long long b0 = __ballot(kh + lane <= hi && kh + lane > bottom_limit && dend[par][1][lane] - min_distance <= P.max_dist_thr);
-            if (b0) rhi = kh + 63 - __builtin_clzll(b0);
-            else for (int k0 = kh - 1; k0 > bottom_limit; k0 -= 64) {
-              const int k = k0 - lane;
-              const bool keep = k > bottom_limit && dist_to_end(plen, tlen, resident ? (int)lm[cslot][k - lo] - 16 : (int)out_m[k - lo], k) - min_distance <= P.max_dist_thr;
-              const unsigned long long b = __ballot(keep);
-              if (b) { rhi = k0 - __builtin_ctzll(b); break; }
-            }
+          if (lane < HDR_INTS) {
+            const int flags = 1 | (has_i ? 2 : 0) | (has_d ? 4 : 0);
+            const int val = lane == 0 ? rlo : lane == 1 ? rhi : lane == 2 ? lo : lane == 3 ? flags : lane == 4 ? (int)(uint32_t)(m_at >> 4) : lane == 5 ? w : lane == 6 ? (int)(uint32_t)(id_at >> 4) : (resident ? step : 0);
+            ring_out[lane] = val;
+            if (wave == 0) hdr_out[lane] = val;
           }
-        }
-        if (lane < HDR_INTS) {
-          const int flags = 1 | (has_i ? 2 : 0) | (has_d ? 4 : 0);
-          const int val = lane == 0 ? rlo : lane == 1 ? rhi : lane == 2 ? lo : lane == 3 ? flags : lane == 4 ? (int)(uint32_t)(m_at >> 4) : lane == 5 ? w : lane == 6 ? (int)(uint32_t)(id_at >> 4) : (resident ? step : 0);
-          ring_out[lane] = val;
-          if (wave == 0) hdr_out[lane] = val;
-        }
-        cslot = cslot + 1 == RM ? 0 : cslot + 1; cislot = cislot + 1 == RID ? 0 : cislot + 1;
-        return false;
+          cslot = cslot + 1 == RM ? 0 : cslot + 1; cislot = cislot + 1 == RID ? 0 : cislot + 1;
+          return false;
         };
         if ((fits && all_sources && sources_in_lds && !id_deep) ? step_body(BoolTag<true>()) : step_body(BoolTag<false>())) break;
       }

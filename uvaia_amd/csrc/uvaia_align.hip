@@ -506,7 +506,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
 // are what makes scores of tens of thousands), every character of length difference a gap extension.  The blocks are persistent and
 // take the next query when they finish one, so the last queries to start decide how long the launch's tail is: the dearer half of
 // the pool is started first, in the order it came (all of the dearest at once would also want all of the workspace at once), then
-// the cheaper half in descending order of the estimate.  One block per query.
+// the cheaper half in descending order of the estimate; a small pool is in descending order throughout.  One block per query.
 __global__ __launch_bounds__(256) void expected_cost_kernel(const uint8_t *__restrict__ seqs, const long long *__restrict__ seq_off, int plen, int n, int *__restrict__ cost)
 {
   __shared__ int part[4];
@@ -757,7 +757,10 @@ int uvaia_align_load_block(uvaia_aligner *a, const char *bytes, const int64_t *o
     ACHK(a, hipStreamSynchronize(a->stream));
     for (int i = 0; i < n; i++) order[(size_t)i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
-    std::sort(order.begin(), order.begin() + n / 2);
+    // a pool of fewer than three rounds of blocks stays in descending order throughout (longest first: with so few queries per block
+    // the order is most of the launch's length, and the dearest third of such a pool in flight at once is what the workspace of the
+    // library's choosing holds: measured at 2 000 queries); a larger one would put only its very dearest in flight at once
+    if (a->workspace_request != 0 || (long long)n * 4 > (long long)a->max_blocks * 11) std::sort(order.begin(), order.begin() + n / 2);
     ACHK(a, hipMemcpyAsync(a->d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, a->stream));
   }
   ACHK(a, hipStreamSynchronize(a->stream));

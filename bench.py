@@ -101,6 +101,33 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
+def usable_cores():
+    """Host threads this process may actually run on: the affinity mask and the cgroup CPU quota both bound it (a GPU box hands a
+    rank a share of its host; omp_get_max_threads() reports every core of the machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q_ > 0 and p_ > 0:
+                n = min(n, max(1, int(q_ / p_ + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def oracle_module():
+    """the CPU restatement (oracle/): the checker and the cpu_baseline leg, never part of a timed GPU step"""
+    if os.path.join(ROOT, "tests") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    return O
+
+
 def survey_bytes_per_ref(nchar, mode):
     """SURVEY 8d's implementation-independent figure: ceil(L*b/8) bytes per reference (14 952 at 4 bits; 2 bits + validity plane: 11 214)"""
     return (nchar * 4 + 7) // 8 if mode == "iupac" else (nchar * 2 + 7) // 8 + (nchar + 7) // 8
@@ -157,8 +184,9 @@ def attach_pmc_traffic(roofline, n_query, refs, pool, mode):
             roofline["issue"] = e["issue"]
 
 
-def single_gpu_workload(hostlib, n_query, refs, mode, nbest, pool, steps, warmup, nchar, seed, preset, device, qt=0, search_only=False):
-    """One resident-database workload on one GPU (no exchange): returns the figures of a sweep entry.  Also used by the headline."""
+def single_gpu_workload(hostlib, n_query, refs, mode, nbest, pool, steps, warmup, nchar, seed, preset, device, qt=0, search_only=False, parity_refs=0):
+    """One resident-database workload on one GPU (no exchange): returns the figures of a sweep entry.  parity_refs > 0: a sample of
+    that many references of the same database goes through the same sequence of calls and is compared with the oracle."""
     gen = hostlib.Synth(nchar, seed=seed, preset=preset)
     qseqs, _ = gen.generate_bytes(QUERY_INDEX0, n_query)
     qnames = ["query_%d" % i for i in range(n_query)]
@@ -207,10 +235,15 @@ def single_gpu_workload(hostlib, n_query, refs, mode, nbest, pool, steps, warmup
         "db_load_s": round(load_s, 2), "query_prepare_s": round(t1 - t0, 2), "engine_open_s": round(t2 - t1, 2),
     }
     eng.close()
+    if parity_refs > 0:
+        from uvaia_amd import capi
+        n_s = min(parity_refs, refs)
+        out["parity"] = parity_on_timed_path(oracle_module(), capi, pq, gen, 0, qseqs, qnames, mode, pool, nbest, n_s, device, qt)
+        out["parity_sample"] = "the first %d references of this database through db_append -> db_rederive -> search_resident: heaps, tolerances and dump flags equal the oracle's" % n_s
     return out
 
 
-def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset, device):
+def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset, device, parity_refs=0):
     """uvaiaball's radius search (src/ball.c:248-259, src/fastaseq.c:660-696) over an HBM-resident database: references per second,
     and how many of them the search had to compare with the queries themselves (the others stop at the queries' consensus)."""
     gen = hostlib.Synth(nchar, seed=seed, preset=preset)
@@ -238,6 +271,14 @@ def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset
            "whole_search_GBps": round(refs * sb * steps / elapsed / 1e9, 1), "whole_search_frac_of_hbm_peak": round(refs * sb * steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
            "query_prepare_s": round(t1 - t0, 2)}
     eng.close()
+    if parity_refs > 0:
+        O = oracle_module()
+        n_s = min(parity_refs, refs)
+        sample, _ = gen.generate_bytes(0, n_s)
+        oq = O.Query(qseqs, ["query_%d" % i for i in range(n_query)], dist=dist, acgt=(mode == "acgt"), is_ball=True)
+        md_want, _keep = oq.ball(sample, ambig_r=0.001)
+        out["parity"] = bool(oq.ntax == pq.ntax and np.array_equal(md[:n_s], md_want))
+        out["parity_sample"] = "cq->mindist of the first %d references (src/ball.c:248-251) equals the oracle's" % n_s
     return out
 
 
@@ -291,11 +332,12 @@ def align_workload(hostlib, n_query, steps, nchar, seed, preset, device, n_cpu, 
            "value": round(n_query * steps / elapsed, 1), "unit": "queries/s", "ms_per_pool": round(1e3 * elapsed / steps, 3), "steps": steps,
            "kernel_ms_per_pool": round(kernel_ms / steps, 3), "kernel": "wfa_align_kernel", "passes": st["passes"],
            "cells_per_query": round(st["cells"] / n_query), "median_score": int(np.median(score)), "max_score": int(score.max()),
-           "cell_updates_per_s": round(st["cells"] * steps / elapsed), "wavefront_bytes_per_cell": 33,
-           "wavefront_GBps": round(st["wavefront_bytes"] * steps / elapsed / 1e9, 1), "frac_of_hbm_peak": round(st["wavefront_bytes"] * steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+           "cell_updates_per_s": round(st["cells"] * steps / elapsed), "bound": "issue",
+           "lds_plus_hbm_bytes_per_cell": 33, "lds_plus_hbm_GBps": round(st["wavefront_bytes"] * steps / elapsed / 1e9, 1),
+           "hbm_bytes_per_cell": 5, "hbm_GBps": round(5.0 * st["cells"] * steps / elapsed / 1e9, 1), "frac_of_hbm_peak": round(5.0 * st["cells"] * steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
            "note": "a query is a chain of one dependent step per score (thousands; N runs cost 4 per site), 1 000-2 500 diagonals wide for most of them: one block of four waves "
                    "per query, the wavefronts of the last steps in LDS, a step = five earlier offsets per cell + extension + one LDS barrier; per cell 5 bytes go to memory for the "
-                   "backtrace (M offset + provenance byte), 8 are I/D offsets, 20 are read (wavefront_GBps counts these 33 algorithmic bytes; with LDS residency only the 5 reach HBM).  Rows and scores equal the CPU restatement's (oracle/wfa_oracle.c; parity unpinned beyond "
+                   "backtrace (M offset + provenance byte: hbm_GBps / frac_of_hbm_peak), 8 are I/D offsets and 20 are read, all of which stay in LDS (lds_plus_hbm_GBps counts all 33); the kernel is bound by instruction issue, not by HBM.  Rows and scores equal the CPU restatement's (oracle/wfa_oracle.c; parity unpinned beyond "
                    "the optimal gap-affine score)"}
     if os.path.join(ROOT, "tests") not in sys.path:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -304,36 +346,51 @@ def align_workload(hostlib, n_query, steps, nchar, seed, preset, device, n_cpu, 
     g_score, g_rows = O.uvaialign_batch(ref, [seqs[i] for i in pick])
     out["parity_on_sample"] = bool(np.array_equal(g_score, score[pick]) and np.array_equal(g_rows, rows[pick]))
     if n_cpu > 0:
-        sample = seqs[:n_cpu]
-        threads = O.lib().orc_max_threads()
-        t0 = time.perf_counter(); O.uvaialign_batch(ref, sample); t_all = time.perf_counter() - t0
-        one = sample[:max(8, n_cpu // 64)]
+        omp_max = O.lib().orc_max_threads()
+        threads = min(usable_cores(), omp_max)
+        # at least 64 queries per thread (or the whole pool), started dearest first as the GPU path starts them: with a handful of
+        # queries per thread the few N-rich ones (scores of tens of thousands) set the wall time
+        n_s = min(n_query, max(n_cpu, 64 * threads))
+        cost = np.array([len(q_) - sum(q_.count(b) for b in (b"A", b"C", b"G", b"T")) for q_ in seqs[:n_s]])
+        sample = [seqs[i] for i in np.argsort(-cost, kind="stable")]
+        t0 = time.perf_counter(); O.uvaialign_batch(ref, sample, threads=threads); t_all = time.perf_counter() - t0
+        one = seqs[:max(16, min(64, n_s // 64))]
         t0 = time.perf_counter(); O.uvaialign_batch(ref, one, threads=1); t_one = time.perf_counter() - t0
         O.lib().orc_set_threads(threads)
-        out["cpu_baseline"] = {"value": round(len(sample) / t_all, 1), "unit": "queries/s", "cores": threads, "kind": "port",
-                               "sample": "the first %d queries of the same pool, OpenMP over %d threads, %.1f s" % (len(sample), threads, t_all),
-                               "value_1_thread": round(len(one) / t_one, 1), "sample_1_thread": "the first %d queries, 1 thread, %.1f s" % (len(one), t_one)}
+        out["cpu_baseline"] = {"value": round(len(sample) / t_all, 1), "unit": "queries/s", "cores": threads, "kind": "port", "host_hardware_threads": omp_max,
+                               "sample": "the first %d queries of the same pool, dearest first, OpenMP (dynamic schedule) over %d threads = the cores this process may use, %.1f s; "
+                                         "an unoptimised restatement of the published algorithm, not the WFA library" % (len(sample), threads, t_all),
+                               "value_1_thread": round(len(one) / t_one, 1), "value_1_thread_x_cores": round(threads * len(one) / t_one, 1),
+                               "sample_1_thread": "the first %d queries, 1 thread, %.1f s" % (len(one), t_one)}
     return out
 
 
 def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_timed, n_one):
-    """The oracle's restatement of the reference loops (src/nearest.c:249-330) on the host cores, with the heaps in the state a long
-    run spends its time in: `n_warm` references are fed untimed (heaps fill, tolerances settle: the early exits of
-    src/nearest.c:488-496 fire), then `n_timed` references are timed on all threads and `n_one` more on one thread."""
-    import ctypes as C
+    """The oracle's restatement of the reference loops (src/nearest.c:249-330) on the host cores, in the reference's configuration:
+    batches of 64 x threads references (its default --pool, src/nearest.c:81) capped at the workload's own --pool, one OpenMP thread
+    per core this process may use.  The heaps are in the state a long run spends its time in: `n_warm` references are fed untimed
+    (heaps fill, tolerances settle: the early exits of src/nearest.c:488-496 fire), then `n_timed` references are timed on all
+    threads and `n_one` more on one thread (same warm state, same batch size)."""
     L = O.lib()
     oq = O.Query(qseqs, qnames, acgt=(mode == "acgt"))
-    cores = L.orc_max_threads()
-    bpool = 256                                         # batches small enough that every timed feed ends on a processed batch, as --pool 256 would
+    omp_max = L.orc_max_threads()
+    cores = min(usable_cores(), omp_max)
+    L.orc_set_threads(cores)
+    bpool = max(64, min(pool, 64 * cores))
     s = L.orc_search_new(oq.ptr, bpool, nbest, 0.5, 0)
 
     def feed(a, n):
-        seqs, _ = gen.generate_bytes(first + a, n)
-        names = ["ref_%d" % (a + i) for i in range(n)]
-        t0 = time.perf_counter()
-        rc = L.orc_search_feed(s, n, O._cstr_array(seqs), O._cstr_array(names), None)
-        assert rc == 0
-        return time.perf_counter() - t0
+        t_total = 0.0
+        for b in range(a, a + n, 8192):
+            m = min(8192, a + n - b)
+            seqs, _ = gen.generate_bytes(first + b, m)
+            names = ["ref_%d" % (b + i) for i in range(m)]
+            arr_s, arr_n = O._cstr_array(seqs), O._cstr_array(names)
+            t0 = time.perf_counter()
+            rc = L.orc_search_feed(s, m, arr_s, arr_n, None)
+            t_total += time.perf_counter() - t0
+            assert rc == 0
+        return t_total
 
     n_warm, n_timed, n_one = [(x + bpool - 1) // bpool * bpool for x in (n_warm, n_timed, n_one)]      # whole batches only
     try:
@@ -341,13 +398,16 @@ def cpu_baseline(O, gen, first, qseqs, qnames, mode, pool, nbest, n_warm, n_time
         t_all = feed(n_warm, n_timed)
         out = {"value": round(n_timed / t_all, 2), "unit": "ref-seqs/s", "cores": cores, "kind": "port",
                "sample": "%d references of the same database vs the same %d queries after %d untimed warm-up references (heaps full), "
-                         "batches of %d, OpenMP over %d threads, %.1f s" % (n_timed, oq.ntax, n_warm, bpool, cores, t_all)}
+                         "batches of %d (the reference's default pool of 64 x threads, src/nearest.c:81), OpenMP over %d threads = the cores this "
+                         "process may use (the host reports %d hardware threads), %.1f s" % (n_timed, oq.ntax, n_warm, bpool, cores, omp_max, t_all),
+               "host_hardware_threads": omp_max}
         if n_one > 0:
             L.orc_set_threads(1)
             t_one = feed(n_warm + n_timed, n_one)
             L.orc_set_threads(cores)
             out["value_1_thread"] = round(n_one / t_one, 2)
-            out["sample_1_thread"] = "the next %d references, same warm state, 1 thread, %.1f s" % (n_one, t_one)
+            out["value_1_thread_x_cores"] = round(cores * n_one / t_one, 2)
+            out["sample_1_thread"] = "the next %d references, same warm state and batch size, 1 thread, %.1f s" % (n_one, t_one)
     finally:
         L.orc_search_del(s)
     try:
@@ -635,13 +695,14 @@ def main():
     sweep = ball = aligned = None
     if rank == 0 and world == 1 and not emu and not args.no_sweep:
         sweep = []
-        for nq_s, mode_s, steps_s in ((1, "iupac", 5), (4, "iupac", 5), (16, "iupac", 5), (10000, "acgt", 2)):
-            e = single_gpu_workload(hostlib, nq_s, args.sweep_refs, mode_s, args.nbest, args.sweep_refs if nq_s <= 16 else args.pool,
-                                    steps_s, 1, args.nchar, args.seed, args.preset, local_rank)
+        # (queries, mode, steps, references of the in-run oracle check: the oracle's cost grows with the query count)
+        for nq_s, mode_s, steps_s, par_s in ((1, "iupac", 5, 4096), (4, "iupac", 5, 4096), (16, "iupac", 5, 4096), (64, "iupac", 5, 2048), (10000, "acgt", 2, 768)):
+            e = single_gpu_workload(hostlib, nq_s, args.sweep_refs, mode_s, args.nbest, args.sweep_refs if nq_s <= 64 else args.pool,
+                                    steps_s, 1, args.nchar, args.seed, args.preset, local_rank, parity_refs=0 if args.no_parity else par_s)
             if (nq_s, args.sweep_refs, args.nchar, args.nbest, mode_s) == (10000, 1000000, 29903, 100, "acgt"):
                 e["workload"] = "BASELINE config[2]: " + e["workload"]
             sweep.append(e)
-        ball = ball_workload(hostlib, 1000, args.sweep_refs, 2, "iupac", 3, args.nchar, args.seed, args.preset, local_rank)
+        ball = ball_workload(hostlib, 1000, args.sweep_refs, 2, "iupac", 3, args.nchar, args.seed, args.preset, local_rank, parity_refs=0 if args.no_parity else 8192)
         if args.align_queries > 0:
             aligned = align_workload(hostlib, args.align_queries, 3, args.nchar, args.seed, args.preset, local_rank, args.align_cpu_queries)
 
@@ -683,8 +744,17 @@ def main():
         sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+    failed = []
     if parity is False:
-        raise SystemExit("bench.py: the timed path disagrees with the oracle on the sample")
+        failed.append("headline")
+    if rank == 0:
+        failed += ["sweep[%d]" % i for i, e in enumerate(sweep or []) if e.get("parity") is False]
+        if ball and ball.get("parity") is False:
+            failed.append("ball")
+        if aligned and aligned.get("parity_on_sample") is False:
+            failed.append("align")
+    if failed:
+        raise SystemExit("bench.py: the GPU path disagrees with the oracle on the sample of: " + ", ".join(failed))
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ typedef struct uvaia_aligner uvaia_aligner;
 
 /* affine_penalties_t + the reduction arguments of affine_wavefronts_new_reduced (src/align.c:305-309) */
 typedef struct {
-  int mismatch, gap_opening, gap_extension;      /* match is 0 (src/align.c:305); all > 0, mismatch and opening + extension below 64 */
+  int mismatch, gap_opening, gap_extension;      /* match is 0 (src/align.c:305); mismatch and extension > 0, opening >= 0, mismatch and opening + extension below 64 */
   int min_wavefront_length;                      /* <= 0: complete wavefronts (no reduction) */
   int max_distance_threshold;
   size_t workspace_bytes;                        /* device memory for the wavefronts of the queries in flight; 0 = starts at 4 GB and grows,

@@ -152,6 +152,23 @@ def test_ball_over_the_resident_database_matches_oracle(acgt):
         assert keep.sum() == (md <= q.dist).sum()
 
 
+@pytest.mark.parametrize("acgt", [False, True])
+def test_seq_ball_against_query_structure_one_sequence_api(acgt):
+    """the reference header's one-sequence entry point of the radius search (src/fastaseq.h:78, src/fastaseq.c:660-696), served by
+    the GPU engine the host library keeps for the query set; a second query set replaces the engine"""
+    from uvaia_amd import hostlib
+    refs, root, cols = F.synth_alignment(60, 2000, seed=71, p_snp=0.003)
+    for seed, dist in ((72, 2), (73, 9)):
+        qs, _, _ = F.synth_alignment(9, 2000, seed=seed, root=root, poly_cols=cols, p_snp=0.003)
+        names = ["q%d" % i for i in range(len(qs))]
+        q = O.Query(qs, names, dist=dist, acgt=acgt, is_ball=True)
+        md_want, _ = q.ball(refs, ambig_r=0.001)
+        pq = hostlib.PreparedQuery(qs, names, dist=dist, acgt=acgt, is_ball=True)
+        assert pq.ntax == q.ntax
+        got = [pq.seq_ball(r, dist + 1) for r in refs]
+        assert got == list(md_want), (acgt, dist)
+
+
 def test_uvaiaball_cli_matches_oracle(files):
     d, qn, qs, rnames, rseqs = files
     out = str(d / "ball_out")

@@ -244,3 +244,16 @@ def test_generator_is_deterministic_and_shaped():
     assert np.array_equal(want, non_n[:50])
     clean = H.Synth(29903, seed=20241008, preset=1).generate(0, 500)[1]
     assert np.median(1.0 - clean / 29903.0) < 0.03
+
+
+def test_quick_pairwise_score_acgt_and_valid_equals_oracle():
+    """the one-pair entry point of the reference's header (src/fastaseq.h:74, src/fastaseq.c:585-596) against the oracle's
+    restatement: every truncation point, every character of the alphabet on either side"""
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACGTNMRWSYKVHDB-X?O.acgtn", dtype=np.uint8)
+    for n in (1, 7, 64, 333):
+        a = alpha[rng.integers(0, len(alpha), size=n)].tobytes()
+        b = alpha[rng.integers(0, len(alpha), size=n)].tobytes()
+        idx = sorted(rng.choice(n, size=max(1, n * 2 // 3), replace=False).tolist())
+        for maxdist in (0, 1, 2, 5, 2 ** 31 - 1):
+            assert H.score_acgt_and_valid(a, b, idx, maxdist) == O.score_acgt(a, b, maxdist, idx), (n, maxdist)

@@ -116,6 +116,33 @@ def test_config2_regime_acgt_many_query_tiles_equal_oracle():
         assert list(np.nonzero(ent)[0]) == list(gold.saved)
 
 
+def test_config2_regime_10000_queries_acgt_equal_oracle():
+    """(b') BASELINE config[2]'s own query count: 10 000 generator queries (157 super-tiles of 64, rare-column cap clamped at 64,
+    several hundred dense polymorphic columns) x 2 304 references, --acgt, k = 100, through db_append -> db_rederive ->
+    search_resident with the default switches; heaps, tolerances and dump flags against the oracle (src/nearest.c:442-477)."""
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(QUERY_INDEX0, 10000)
+    qn = _names(10000, "query_")
+    refs, _ = gen.generate_bytes(0, 2304)
+    oq = O.Query(qs, qn, acgt=True)
+    gold = O.search(oq, refs, _names(len(refs)), pool=2304, nbest=100, ambig_r=0.5)
+    pq = hostlib.PreparedQuery(qs, qn, acgt=True)
+    assert pq.ntax == oq.ntax == 10000
+    with pq.open_engine(nbest=100, max_pool=2304) as eng:
+        assert eng.scan_variant() == 2
+        _load(eng, gen, 0, len(refs))
+        for _ in range(2):
+            rows, T, ent = _timed_step(eng, 2304)
+            assert rows == _want(gold, oq.ntax) and T == gold.final_T
+            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+    # the same queries, sub-slices that are not tile aligned and wrap the ring of counter buffers
+    with pq.open_engine(nbest=100, max_pool=2304, tuning={"subslice_refs": 500}) as eng:
+        _load(eng, gen, 0, len(refs))
+        rows, T, ent = _timed_step(eng, 2304)
+        assert rows == _want(gold, oq.ntax) and T == gold.final_T
+        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
 def _heap_pairs(rows):
     """{ordinal: [(query, scores)]} of everything the heaps hold"""
     by_ref = {}
@@ -164,6 +191,55 @@ def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt, n_r
     sample = sorted(rng.choice(sorted(by_ref), size=min(192, len(by_ref)), replace=False).tolist())
     seqs = [gen.generate(o, 1)[0][0].tobytes() for o in sample]
     oq = O.Query(qs, qn, acgt=acgt)
+    want = oq.allpairs(seqs)
+    checked = 0
+    for j, o in enumerate(sample):
+        for iq, s in by_ref[o]:
+            assert tuple(int(x) for x in want[j, iq]) == s, "reference %d, query %d" % (o, iq)
+            checked += 1
+    assert checked >= len(sample)
+
+
+def test_full_size_config2_three_ways_agree_and_scores_are_the_oracles():
+    """(c') BASELINE config[2] at its full size: 10 000 queries x 1 000 000 references, --acgt, k = 100, pool 65 536 (what
+    bench.py's sweep times).  The oracle cannot finish that, so: the timed step (rederive on its own streams overlapping the
+    sub-slice scans), the same step with every launch serialised and the streaming push path leave identical heaps, tolerances and
+    dump flags; every heap is full; and the six scores of heap entries are the oracle's untruncated pair scores (every entry that
+    refers to one of 160 sampled references)."""
+    n_ref, pool, nq = 1000000, 65536, 10000
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(QUERY_INDEX0, nq)
+    qn = _names(nq, "query_")
+    pq = hostlib.PreparedQuery(qs, qn, acgt=True)
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:
+        _load(eng, gen, 0, n_ref)
+        rows, T, ent = _timed_step(eng, pool)
+    with pq.open_engine(nbest=100, max_pool=pool, tuning={"serial": 1}) as eng:
+        _load(eng, gen, 0, n_ref)
+        rows_s, T_s, ent_s = _timed_step(eng, pool)
+    assert rows_s == rows and T_s == T and np.array_equal(ent_s, ent)
+    del rows_s, ent_s
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:              # streaming: sixteen pools of raw characters
+        ent_p = []
+        for a in range(0, n_ref, pool):
+            m = min(pool, n_ref - a)
+            parts = []
+            for b in range(a, a + m, 8192):
+                rows_b, non_n = gen.generate(b, min(8192, a + m - b))
+                parts.append(([rows_b[i].tobytes() for i in range(len(rows_b))], non_n))
+                del rows_b
+            ent_p.append(eng.push([s for p_ in parts for s in p_[0]], non_n=np.concatenate([p_[1] for p_ in parts]), ordinal0=a))
+            del parts
+        n, Tp, sc, od = eng.drain()
+        assert capi.finalise_heaps(n, sc, od) == rows and list(Tp) == T
+        assert np.array_equal(np.concatenate(ent_p), ent)
+    assert all(len(r) == 100 for r in rows)
+    by_ref = _heap_pairs(rows)
+    assert set(by_ref) <= set(np.nonzero(ent)[0].tolist())
+    rng = np.random.default_rng(6)
+    sample = sorted(rng.choice(sorted(by_ref), size=min(160, len(by_ref)), replace=False).tolist())
+    seqs = [gen.generate(o, 1)[0][0].tobytes() for o in sample]
+    oq = O.Query(qs, qn, acgt=True)
     want = oq.allpairs(seqs)
     checked = 0
     for j, o in enumerate(sample):

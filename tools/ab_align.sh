@@ -8,6 +8,8 @@ N=${1:-2000}; shift
 C=uvaia_amd/csrc; FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value"
 [ -f $C/build/uvaia_gpu.o ] || make -C $C -s || exit 1
 cp uvaia_amd/lib/libuvaia_gpu.so /tmp/libuvaia_gpu_default.so || exit 1
+# whatever ends the script (a failed variant, a timeout from outside, a signal), the tree gets its default library back
+trap 'cp /tmp/libuvaia_gpu_default.so uvaia_amd/lib/libuvaia_gpu.so' EXIT INT TERM
 for v in "$@"; do
   nw=${v%%:*}; g=${v##*:}
   hipcc $FL -DWFA_NW=$nw -DWFA_GROUP=$g -c $C/uvaia_align.hip -o /tmp/v_align.o 2> /tmp/v_align.err && hipcc $FL -shared -o uvaia_amd/lib/libuvaia_gpu.so $C/build/uvaia_gpu.o /tmp/v_align.o || { cat /tmp/v_align.err; exit 1; }

@@ -3,6 +3,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/ab_libs; mkdir -p $O
 cp uvaia_amd/lib/libuvaia_gpu.so /tmp/libuvaia_gpu_default.so || exit 1
+# whatever ends the script (a failed variant, a timeout from outside, a signal), the tree gets its default library back
+trap 'cp /tmp/libuvaia_gpu_default.so uvaia_amd/lib/libuvaia_gpu.so' EXIT INT TERM
 for rep in 1 2; do
 for lib in uvaia_amd/lib/variants/libuvaia_gpu_*.so; do
   v=$(basename $lib .so); v=${v#libuvaia_gpu_}

@@ -143,7 +143,12 @@ main (int argc, char **argv)
             failed = d;
           }
         }
-        if (failed >= 0) biomcmc_error ("%s", uvaia_align_last_error (gpu[failed]));
+        if (failed >= 0) {   /* what was aligned so far stays a complete file: close the stream before giving up */
+          const int a = (int) ((long long) fill * failed / n_devices), b = (int) ((long long) fill * (failed + 1) / n_devices);
+          if (!to_screen) biomcmc_close_compress (outstream);
+          biomcmc_error ("%s (counted from sequence %s, the first of the %d handed to device %d; %d sequences were written before)",
+                         uvaia_align_last_error (gpu[failed]), name[a], b - a, failed, n_output);
+        }
         for (int c = 0; c < fill; c++) {
           const char *row = aln + (size_t) c * (aln_length + 1);
           n_output++;

@@ -61,6 +61,7 @@ main (int argc, char **argv)
   int64_t time0[2];
   biomcmc_get_time (time0);
   alignment aln = read_fasta_alignment_from_file (qfile, 0xf);
+  uvaia_set_prepare_device (device);
   query_t query = uvaia_prepare_query (aln, trim, dist, acgt, ambig_q, keep_resolved, 1);
   fprintf (stderr, "Query database now composed of %d valid references, after removing redundant (%s resolved) sequences.\n", query->aln->ntax, keep_resolved ? "less" : "more");
   if (query->aln->ntax < 1) biomcmc_error ("No valid reference sequences found. Please check file %s.", qfile);

@@ -36,9 +36,18 @@ readfasta_t new_readfasta (const char *seqfilename);
 int readfasta_next (readfasta_t rfas);
 void del_readfasta (readfasta_t rfas);
 
+/* the --acgt scoring kernel over the sites idx[0..nsites): score[0] = sites where both are ACGT and differ, score[1] = sites where
+ * both are ACGT; stops once score[0] reaches maxdist (src/fastaseq.c:585-596, src/fastaseq.h:74).  Scalar, on the host: the one-pair
+ * entry point the reference's header exports; the batch loops of src/nearest.c:293-306 run on the GPU (include/uvaia_gpu.h). */
+void quick_pairwise_score_acgt_and_valid (char *s1, char *s2, size_t nsites, int maxdist, int *score, size_t *idx);
 int quick_count_sequence_non_N (char *s, size_t nsites);   /* valid sites over the given span */
 int quick_count_sequence_acgt (char *s, size_t nsites);    /* ACGT sites (src/fastaseq.c:650-656; not in the reference's header) */
 
+/* for uvaiaball (src/fastaseq.h:78, src/fastaseq.c:660-696): *min_dist = what the reference leaves there for ONE sequence and radius
+ * ball_radius.  Runs on the GPU through uvaia_gpu_ball() with an engine kept for `qu` (made at the first call, dropped by
+ * del_query_structure or by a call with another query set); errors are fatal, as everywhere in this API.  The batch loop of
+ * src/ball.c:248-251 should call uvaia_gpu_ball() with the whole batch instead. */
+void seq_ball_against_query_structure (char **seq, int *min_dist, int ball_radius, query_t qu);
 query_t new_query_structure_from_fasta (char *filename, int trim, int dist, int acgt);
 query_t new_query_structure_from_alignment (alignment aln, int trim, int dist, int acgt);   /* takes ownership of aln */
 void del_query_structure (query_t qu);

@@ -92,3 +92,28 @@ uvaia_gpu_collect_heaps (uvaia_gpu_ctx *ctx, heap_t *heap, const char *(*name_of
 int
 uvaia_gpu_group_collect_heaps (uvaia_gpu_group *group, heap_t *heap, const char *(*name_of) (int64_t, void *), void *user)
 { return collect_heaps (NULL, group, heap, name_of, user); }
+
+/* ---- seq_ball_against_query_structure (src/fastaseq.h:78): the reference's one-sequence entry point of the radius search, kept for
+ * callers of the fastaseq API.  The engine of the query set is opened at the first call and reused until the query set goes away. */
+static struct { query_t qu; uvaia_gpu_ctx *ctx; } ball_engine = {NULL, NULL};
+
+void
+uvaia_gpu_forget_query (query_t qu)
+{
+  if (!ball_engine.ctx || (qu && ball_engine.qu != qu)) return;
+  uvaia_gpu_close (ball_engine.ctx);
+  ball_engine.ctx = NULL; ball_engine.qu = NULL;
+}
+
+void
+seq_ball_against_query_structure (char **seq, int *min_dist, int ball_radius, query_t qu)
+{
+  if (!seq || !*seq || !min_dist || !qu) biomcmc_error ("seq_ball_against_query_structure: NULL argument");
+  if (ball_engine.qu != qu) {
+    uvaia_gpu_forget_query (NULL);
+    if (uvaia_gpu_open_query (&ball_engine.ctx, qu, 2, -1, 64)) biomcmc_error ("radius search on the GPU: %s", uvaia_gpu_last_error (NULL));
+    ball_engine.qu = qu;
+  }
+  const char *one[1] = {*seq};
+  if (uvaia_gpu_ball (ball_engine.ctx, one, 1, ball_radius, min_dist)) biomcmc_error ("radius search on the GPU: %s", uvaia_gpu_last_error (ball_engine.ctx));
+}

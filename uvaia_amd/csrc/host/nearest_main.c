@@ -154,6 +154,7 @@ main (int argc, char **argv)
   /* 1. queries: read, quality filter, column classes, ordering, optional pruning */
   alignment aln = read_fasta_alignment_from_file (o.query, 0xf);
   fprintf (stderr, "Finished reading %d query references in %lf secs;\n", aln->ntax, biomcmc_update_elapsed_time (time0));
+  uvaia_set_prepare_device (o.n_devices ? o.devices[0] : o.device);
   query_t query = uvaia_prepare_query (aln, o.trim, 1, o.acgt, o.ambig_q, o.keep_resolved, 0);
   fprintf (stderr, "Query database composed of %d valid references, after excluding low quality%s.\n", query->aln->ntax,
            o.keep_resolved ? " and redundant (less resolved) sequences" : "");

@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+static int prepare_device = -1; /* GPU the preparation's device steps run on (-1: the current one); the command lines pass --device */
+
 /* exclude_redundant_query_sequences (src/fastaseq.c:797-841) with its O(Q^2) pair test on the device: the engine is opened on
  * the still unpruned query set, the queries go through it as if they were references (uvaia_gpu_agree_on_polymorphic), and the
  * order-dependent walk over the pairs runs here on the finished matrix.  Same survivors as the host-only function. */
@@ -13,7 +15,7 @@ exclude_redundant_query_sequences_device (query_t query, int keep_resolved)
   const int n = query->aln->ntax;
   const size_t batch = n < 2048 ? (size_t) n : 2048;
   uvaia_gpu_ctx *gpu = NULL;
-  if (uvaia_gpu_open_query (&gpu, query, 1, -1, batch))
+  if (uvaia_gpu_open_query (&gpu, query, 1, prepare_device, batch))
     biomcmc_error ("pruning redundant queries on the GPU: %s (uvaia_set_prune_mode(1) runs the serial host loop instead)", uvaia_gpu_last_error (NULL));
   unsigned char *agree = (unsigned char *) biomcmc_malloc ((size_t) n * n);
   for (int a = 0; a < n; a += (int) batch) {
@@ -32,6 +34,7 @@ exclude_redundant_query_sequences_device (query_t query, int keep_resolved)
 #define UVAIA_PRUNE_DEVICE_FROM 512
 #define UVAIA_COLUMNS_DEVICE_FROM 2048
 static int prune_mode = 0;     /* 0 = by query count, 1 = host, 2 = device */
+void uvaia_set_prepare_device (int device) { prepare_device = device < 0 ? -1 : device; }
 void uvaia_set_prune_mode (int mode) { prune_mode = (mode == 1 || mode == 2) ? mode : 0; }
 static int
 prune_on_device (int ntax)
@@ -49,7 +52,7 @@ create_query_indices_where_it_pays (query_t query)
   if (!device || L < 1) { create_query_indices (query); return; }
   char *consensus = (char *) biomcmc_malloc ((size_t) L);
   unsigned char *missing = (unsigned char *) biomcmc_malloc ((size_t) L);
-  if (uvaia_gpu_query_columns ((const char *const *) query->aln->character->string, n, L, query->trim, query->acgt, -1, consensus, missing))
+  if (uvaia_gpu_query_columns ((const char *const *) query->aln->character->string, n, L, query->trim, query->acgt, prepare_device, consensus, missing))
     biomcmc_error ("column classes of the queries on the GPU: %s (uvaia_set_prune_mode(1) runs the host loop instead)", uvaia_gpu_last_error (NULL));
   create_query_indices_given (query, consensus, missing);
   free (consensus); free (missing);

@@ -14,6 +14,8 @@ query_t uvaia_prepare_query_from_arrays (int ntax, int nchar, const char *const 
 /* where the query preprocessing runs -- the O(Q^2) pair test of exclude_redundant_query_sequences and the O(Q x L) column walk of
  * create_query_indices: 0 = on the device from 512 / 2 048 queries on (default), 1 = host, 2 = device */
 void uvaia_set_prune_mode (int mode);
+/* the GPU those device steps run on (-1 = the current device, the default): what --device / the first of --devices selects */
+void uvaia_set_prepare_device (int device);
 
 #ifdef __cplusplus
 }

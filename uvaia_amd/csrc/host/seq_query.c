@@ -88,6 +88,19 @@ del_readfasta (readfasta_t r)
   free (r);
 }
 
+void
+quick_pairwise_score_acgt_and_valid (char *s1, char *s2, size_t nsites, int maxdist, int *score, size_t *idx)
+{ /* src/fastaseq.c:585-596: both counters advance site by site until the mismatches reach maxdist */
+  int differ = 0, both = 0;
+  for (size_t k = 0; k < nsites && differ < maxdist; k++) {
+    const char a = s1[idx[k]], b = s2[idx[k]];
+    if (!is_site_acgt_pair_valid (a, b)) continue;
+    both++;
+    differ += is_site_acgt_distinct_pair (a, b);
+  }
+  score[0] = differ; score[1] = both;
+}
+
 int
 quick_count_sequence_non_N (char *s, size_t nsites)
 { /* sits in the serial read loop once per reference (src/nearest.c:263): written as byte comparisons the compiler vectorises
@@ -140,10 +153,13 @@ new_query_structure_from_fasta (char *filename, int trim, int dist, int acgt)
   return new_query_structure_from_alignment (read_fasta_alignment_from_file (filename, 0xf), trim, dist, acgt);
 }
 
+void uvaia_gpu_forget_query (query_t qu);     /* gpu_glue.c: the engine seq_ball_against_query_structure keeps for a query set */
+
 void
 del_query_structure (query_t qu)
 {
   if (!qu) return;
+  uvaia_gpu_forget_query (qu);
   free (qu->consensus); free (qu->idx_c); free (qu->idx_m); free (qu->idx);
   del_alignment (qu->aln);
   free (qu);

@@ -56,7 +56,7 @@ constexpr int MAX_HDR_PAGES = 256;
 constexpr int MAX_OWN = 512;             // chunks a query may hold on top of the block's two permanent ones
 constexpr int WL = 2560;                 // widest wavefront kept in LDS (16-bit offsets + 16)
 constexpr int RM = 5, RID = 2;           // LDS slots: M wavefronts of the last RM steps, I and D of the last RID
-enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3, ST_TOOWIDE = 4 };
+enum { ST_OK = 0, ST_OVERFLOW = 1, ST_MAXSCORE = 2, ST_BACKTRACE = 3, ST_TOOWIDE = 4, ST_HDRPAGES = 5 };
 enum { C_DEL_EXT = 0, C_DEL_OPEN = 1, C_INS_EXT = 2, C_INS_OPEN = 3, C_MISMATCH = 4, C_I_EXT = 8, C_D_EXT = 16 };
 
 struct WfaParams { int x, oe, e, min_wf_len, max_dist_thr, max_score, g; };
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TPB) void wfa_align_kernel(const uint8_t *__restric
       if (score / HDR_PAGE_SCORES != (score - P.g) / HDR_PAGE_SCORES || score == 0) {     // a new page of headers
         const int page = score / HDR_PAGE_SCORES;
         size_t at = 0;
-        if (page >= MAX_HDR_PAGES) { status = ST_MAXSCORE; break; }
+        if (page >= MAX_HDR_PAGES) { status = ST_HDRPAGES; break; }
         if (!take(HDR_PAGE_SCORES * HDR_INTS, at)) { status = ST_OVERFLOW; break; }
         if (tid == 0) hdr_page[page] = (uint32_t)(at >> 4);
         __syncthreads();
@@ -642,6 +642,7 @@ int run_passes(uvaia_aligner *a)
     auto look = [&](int i) -> int {
       if (status[(size_t)i] == ST_OVERFLOW) list.push_back(i);
       else if (status[(size_t)i] == ST_MAXSCORE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: alignment score above %d, the size of the reference's score table", i, a->P.max_score);
+      else if (status[(size_t)i] == ST_HDRPAGES) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: alignment score above %d, the most this aligner keeps score headers for (%d pages of %d scores)", i, MAX_HDR_PAGES * HDR_PAGE_SCORES - 1, MAX_HDR_PAGES, HDR_PAGE_SCORES);
       else if (status[(size_t)i] == ST_TOOWIDE) return afail(a, UVAIA_ALIGN_EINVAL, "sequence %d: a wavefront wider than the workspace's chunks hold (%zu bytes each)", i, (size_t)4 << a->chunk_log2);
       else if (status[(size_t)i] != ST_OK) return afail(a, UVAIA_ALIGN_ESTATE, "sequence %d: inconsistent backtrace", i);
       return 0;
@@ -700,14 +701,17 @@ int uvaia_align_open(uvaia_aligner **out, const char *ref, int ref_len, int devi
   uvaia_align_options opt; uvaia_align_default_options(&opt);
   if (opt_in) opt = *opt_in;
   if (opt.mismatch < 1 || opt.gap_opening < 0 || opt.gap_extension < 1 || opt.mismatch >= RING || opt.gap_opening + opt.gap_extension >= RING)
-    return afail(nullptr, UVAIA_ALIGN_EINVAL, "penalties must be positive and below %d (mismatch %d, gap opening %d, gap extension %d)", RING, opt.mismatch, opt.gap_opening, opt.gap_extension);
+    return afail(nullptr, UVAIA_ALIGN_EINVAL, "mismatch and gap extension must be positive, gap opening not negative, mismatch and opening + extension below %d (mismatch %d, gap opening %d, gap extension %d)", RING, opt.mismatch, opt.gap_opening, opt.gap_extension);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return afail(nullptr, UVAIA_ALIGN_ENODEV, "no HIP device: the aligner runs on an MI355X (gfx950) and has no CPU path");
   if (device < 0 || device >= ndev) return afail(nullptr, UVAIA_ALIGN_EINVAL, "device %d out of range (%d devices)", device, ndev);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return afail(nullptr, UVAIA_ALIGN_ENODEV, "cannot query device %d", device);
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return afail(nullptr, UVAIA_ALIGN_ENODEV, "device %d is %s: this library is built for gfx950 only", device, prop.gcnArchName);
+  int caller_device = -1;
+  if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
   if (hipSetDevice(device) != hipSuccess) return afail(nullptr, UVAIA_ALIGN_ENODEV, "cannot select device %d", device);
+  struct RestoreDevice { int d; ~RestoreDevice() { if (d >= 0) hipSetDevice(d); } } restore_{caller_device};   // every later call selects a->device itself
   uvaia_aligner *a = new uvaia_aligner();
   a->device = device; a->plen = ref_len;
   a->P.x = opt.mismatch; a->P.oe = opt.gap_opening + opt.gap_extension; a->P.e = opt.gap_extension;

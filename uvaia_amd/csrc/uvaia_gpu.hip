@@ -992,8 +992,11 @@ int uvaia_gpu_query_columns(const char *const *seq, int n_query, int nchar, size
   if (!seq || !consensus || !some_missing || n_query < 1 || nchar < 1) return fail(nullptr, UVAIA_GPU_EINVAL, "empty query set");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, UVAIA_GPU_ENODEV, "no HIP device available: the MI355X engine has no CPU fallback");
-  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  int caller_device = -1;
+  if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
+  if (device < 0) device = caller_device < 0 ? 0 : caller_device;
   if (device >= ndev || hipSetDevice(device) != hipSuccess) return fail(nullptr, UVAIA_GPU_ENODEV, "device %d is not usable", device);
+  struct RestoreDevice { int d; ~RestoreDevice() { if (d >= 0) hipSetDevice(d); } } restore_{caller_device};   // no context: the caller's current device is left as it was
   const int lo = (int)std::min<size_t>(trim, (size_t)nchar), hi = std::max(lo, nchar - (int)std::min<size_t>(trim, (size_t)nchar));
   memset(consensus, 'N', (size_t)nchar);
   memset(some_missing, 0, (size_t)nchar);

@@ -84,6 +84,9 @@ def load_library():
     L.del_readfasta.argtypes = [C.POINTER(ReadFasta)]
     L.quick_count_sequence_non_N.restype = C.c_int
     L.quick_count_sequence_non_N.argtypes = [C.c_char_p, C.c_size_t]
+    L.quick_pairwise_score_acgt_and_valid.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.seq_ball_against_query_structure.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, qp]
+    L.uvaia_set_prepare_device.argtypes = [C.c_int]
     L.uvaia_synth_new.restype = C.c_void_p
     L.uvaia_synth_new.argtypes = [C.c_int, C.c_uint64, C.c_int]
     L.uvaia_synth_free.argtypes = [C.c_void_p]
@@ -138,11 +141,27 @@ class PreparedQuery:
         eng._keep = self
         return eng
 
+    def seq_ball(self, seq, radius):
+        """seq_ball_against_query_structure (src/fastaseq.h:78) for one sequence: what the reference leaves in *min_dist"""
+        one = (C.c_char_p * 1)(seq)
+        md = C.c_int(0)
+        self._L.seq_ball_against_query_structure(one, C.byref(md), int(radius), self.ptr)
+        return md.value
+
     def __del__(self):
         try:
             self._L.del_query_structure(self.ptr)
         except Exception:
             pass
+
+
+def score_acgt_and_valid(s1, s2, idx, maxdist=2 ** 31 - 1):
+    """quick_pairwise_score_acgt_and_valid (src/fastaseq.h:74) over the sites idx"""
+    L = load_library()
+    arr = (C.c_size_t * len(idx))(*[int(i) for i in idx])
+    out = (C.c_int * 2)()
+    L.quick_pairwise_score_acgt_and_valid(s1, s2, len(idx), int(maxdist), out, arr)
+    return list(out)
 
 
 def set_prune_mode(mode):

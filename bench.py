@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--rederive-streams", type=int, default=0, help="tuning: streams the chunks of uvaia_gpu_db_rederive alternate over (0 = the library's choice)")
     ap.add_argument("--align-queries", type=int, default=10000, help="queries of the uvaialign record (BASELINE config[4]; 0 = skip)")
     ap.add_argument("--align-only", action="store_true", help="only the uvaialign record (profiling runs); prints {\"align\": ...}")
+    ap.add_argument("--ball-only", action="store_true", help="only the uvaiaball record (profiling runs); prints {\"ball\": ...}")
     ap.add_argument("--align-cpu-queries", type=int, default=1024, help="queries of the uvaialign CPU-baseline sample (0 = skip)")
     return ap.parse_args(argv)
 
@@ -539,6 +540,10 @@ def main():
     if args.align_only:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         print(json.dumps({"align": align_workload(hostlib, args.align_queries, args.steps, args.nchar, args.seed, args.preset, local_rank, args.align_cpu_queries)}))
+        return
+    if args.ball_only:
+        print(json.dumps({"ball": ball_workload(hostlib, args.queries, args.sweep_refs, 2, args.mode, args.steps, args.nchar, args.seed, args.preset, local_rank,
+                                                parity_refs=0 if args.no_parity else 8192)}))
         return
     dist = None
     if world > 1:

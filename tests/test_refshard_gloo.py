@@ -64,12 +64,11 @@ class RefShardOracleEngine:
         assert first // self.piece == (first + n - 1) // self.piece
         t0 = first // 64
         tiles = (first + n + 63) // 64 - t0
-        cnt = self._view(cnt_ptr, self.rows * tiles * 64 * 2).reshape(self.rows, tiles * 64, 2)
+        cnt = self._view(cnt_ptr, self.rows * tiles * 64).reshape(self.rows, tiles * 64)          # one dword per pair
         tmin = self._view(tmin_ptr, self.rows * tiles * 2).reshape(self.rows, tiles, 2)
         pos = t0 * 64 + np.arange(tiles * 64, dtype=np.int64)
         for q in range(self.rows):
-            cnt[q, :, 0] = (q * 1000003 + pos * 7 + 11) & 0x7FFFFFFF
-            cnt[q, :, 1] = q
+            cnt[q, :] = (q * 1000003 + pos * 7 + 11) & 0x7FFFFFFF
             tmin[q, :, 0] = q
             tmin[q, :, 1] = t0 + np.arange(tiles)
         self.scanned.append((first, n))
@@ -93,12 +92,12 @@ class RefShardOracleEngine:
         t0 = first // 64
         tiles = (first + n + 63) // 64 - t0
         nq = q1 - q0
-        cnt = self._view(cnt_ptr, nq * tiles * 64 * 2).reshape(nq, tiles * 64, 2)
+        cnt = self._view(cnt_ptr, nq * tiles * 64).reshape(nq, tiles * 64)
         tmin = self._view(tmin_ptr, nq * tiles * 2).reshape(nq, tiles, 2)
         pos = t0 * 64 + np.arange(tiles * 64, dtype=np.int64)
         for k in range(nq):
-            assert np.array_equal(cnt[k, :, 0], (((q0 + k) * 1000003 + pos * 7 + 11) & 0x7FFFFFFF).astype(np.int32)), "rows of another query or piece"
-            assert (cnt[k, :, 1] == q0 + k).all() and (tmin[k, :, 0] == q0 + k).all()
+            assert np.array_equal(cnt[k, :], (((q0 + k) * 1000003 + pos * 7 + 11) & 0x7FFFFFFF).astype(np.int32)), "rows of another query or piece"
+            assert (tmin[k, :, 0] == q0 + k).all()
             assert np.array_equal(tmin[k, :, 1], t0 + np.arange(tiles))
         if self.replayed:
             assert first == self.replayed[-1][0] + self.replayed[-1][1], "pieces are replayed in stream order, none skipped"

@@ -56,6 +56,7 @@ constexpr int AMB_STRIDE = AMB_CAP + 1;  // ints per QUERY: count (uncapped) + w
 constexpr int AMB_ROW = 64;            // ints per REFERENCE side row (256 B, one coalesced wave load):
                                        //   [0] count (uncapped)  [1..11] word indices  [12 + 4k + p] plane p of the k-th listed word
 constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
+constexpr uint32_t SCAN3_BIAS = 16384u; // scan3_kernel: bias of a pair's low counter half (what the rare items and, --acgt, the polymorphic columns may take away)
 constexpr int NBUF = 4;                // counter buffers: the scan may run this many slices ahead of the gate/replay
 
 thread_local std::string g_open_error;
@@ -82,10 +83,9 @@ struct uvaia_gpu_ctx {
   size_t derive_pending = 0;          // chunks of the last rederive a scan may still have to wait for
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
   size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
-  int2 *d_cntb[NBUF] = {};                // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
+  uint32_t *d_cntb[NBUF] = {};            // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
   int2 *d_tmin[NBUF] = {};                // per (query, tile of 64 references): {smallest mismatch count, largest ACGT-match count}, one per counter buffer
   int4 *d_rtb[NBUF] = {};                 // per reference of a slice: untruncated consensus pre-score (query sets with constant-and-complete columns), one per counter buffer
-  int *d_mp[NBUF] = {};                   // --acgt: mismatches on the polymorphic columns per pair (dist_unique), one per counter buffer
   int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
   long long slice_tf[NBUF] = {};
   size_t subslice = 32768;                // resident search: pools are cut into slices of this size (exact: see search_resident)
@@ -123,7 +123,8 @@ struct uvaia_gpu_ctx {
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
-  int2 *d_cnt2 = nullptr;        // [nq_pad][pool_pad] two-counter scan output
+  uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 (written for the tiles that can still admit something)
+  int2 *d_thr = nullptr;         // [nq_pad] per query {largest mismatch count held + 1, first key of the worst kept entry}: what the scans filter their output by
   unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
   bool fullscan = false;         // four-counter scan + the replay over it (alignments above 49 000 columns; tuning.scan = UVAIA_GPU_SCAN_WIDE)
   size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
@@ -133,6 +134,9 @@ struct uvaia_gpu_ctx {
   uint32_t *d_pmask = nullptr;   // [W4*4] mask of the polymorphic query columns (query->idx)
   int *d_mindist = nullptr, *d_ball_list = nullptr, *d_ball_cdist = nullptr, *d_ball_n = nullptr; size_t ball_cap = 0;   // radius search: results, the references that go on to the queries
   uint4 *d_ball_tiles = nullptr; size_t ball_tiles_cap = 0; unsigned long long ball_asked = 0;
+  int *d_idx_cols = nullptr; int n_idx = 0, NG4 = 0;       // query->idx (the polymorphic query columns) and the word groups they fill once gathered
+  uint32_t *d_qg = nullptr;                                 // the queries on those columns (kernels_ball.inc), built by the first radius search
+  unsigned long long *d_ball_key = nullptr;                 // per listed reference: first query that ends the reference's loop (query << 32 | distance)
   // heaps / state
   int *d_heap = nullptr, *d_n = nullptr, *d_T = nullptr, *d_snap = nullptr, *d_err = nullptr;
   // batch buffers
@@ -199,6 +203,7 @@ void fill_code_table(uint8_t *t)
 #include "kernels_scan_history.inc"
 #include "kernels_scan3.inc"
 #include "kernels_replay.inc"
+#include "kernels_ball.inc"
 
 // ------------------------------------------------------------------------------------------------------------
 // host side
@@ -240,6 +245,28 @@ int ensure_qpoly(uvaia_gpu_ctx *c)
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) { hipFree(d); return fail(c, UVAIA_GPU_EHIP, "query planes on the polymorphic columns: %s", hipGetErrorString(e)); }
   c->d_qpoly = d;
+  return 0;
+}
+
+// The queries on the columns of query->idx, bit-gathered (kernels_ball.inc): what stage 2 of the radius search compares references with.
+int ensure_qgather(uvaia_gpu_ctx *c)
+{
+  if (c->d_qg) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int NG = c->acgt ? 3 : 5;
+  const size_t n = (size_t)c->nq_pad * c->NG4 * 4 * NG;
+  uint32_t *d = nullptr;
+  HIPCHK(c, hipMalloc(&d, n * 4));
+  hipError_t e = hipMemsetAsync(d, 0, n * 4, c->stream);
+  dim3 grid((unsigned)((c->NG4 * 4 + 63) / 64), (unsigned)c->nq);
+  if (e == hipSuccess) {
+    if (c->acgt) hipLaunchKernelGGL((ball_gather_queries_kernel<true>), grid, dim3(64), 0, c->stream, c->d_qp, c->nq, c->W4, c->d_idx_cols, c->n_idx, c->NG4, d);
+    else         hipLaunchKernelGGL((ball_gather_queries_kernel<false>), grid, dim3(64), 0, c->stream, c->d_qp, c->nq, c->W4, c->d_idx_cols, c->n_idx, c->NG4, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { hipFree(d); return fail(c, UVAIA_GPU_EHIP, "query planes on the polymorphic columns: %s", hipGetErrorString(e)); }
+  c->d_qg = d;
   return 0;
 }
 
@@ -312,8 +339,8 @@ int launch_scan(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first, int 
 
 // rt (nullable unless the query set has constant-and-complete columns): the untruncated consensus pre-score of the slice's references,
 // by the packed-plane scans themselves or, next to the column-compressed scan, by consensus_rt_kernel on the same stream
-int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, int2 *out, int ppad, double bytes, hipStream_t stream,
-                 int2 *tmin, int r_lo, int r_hi, int *mp, int4 *rt)
+int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, long long tile_first, int n_tiles, uint32_t *out, int ppad, double bytes, hipStream_t stream,
+                 int2 *tmin, int r_lo, int r_hi, int4 *rt)
 {
   if (n_tiles <= 0) return 0;
   if (!stream) stream = c->stream;
@@ -352,7 +379,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int st_first = c->act_q0 / QS, n_st = (c->act_q1 + QS - 1) / QS - st_first;
     const int R = c->scan_R;
     dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
-#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, mp, st_first)
+#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, c->d_thr, cons ? 0 : 1, st_first)
 #define SCAN3_NW(A, RR) { if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR); else SCAN3_LAUNCH(4, A, RR); }
     if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
     else        { if (c->acgt) SCAN3_NW(true, 1) else SCAN3_NW(false, 1) }
@@ -364,7 +391,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-#define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt)
+#define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt, c->d_thr)
 #define LAUNCH_QT(K, CN) switch (qt2) { case 1: LAUNCH(K, 1, CN); break; case 2: LAUNCH(K, 2, CN); break; case 4: LAUNCH(K, 4, CN); break; case 8: LAUNCH(K, 8, CN); break; default: LAUNCH(K, 16, CN); }
   if (c->acgt) { if (cons) { LAUNCH_QT(scan2_acgt_kernel, true) } else { LAUNCH_QT(scan2_acgt_kernel, false) } }
   else         { if (cons) { LAUNCH_QT(scan2_iupac_kernel, true) } else { LAUNCH_QT(scan2_iupac_kernel, false) } }
@@ -421,11 +448,11 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (c->acgt) hipLaunchKernelGGL((replay_kernel<true>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
     else         hipLaunchKernelGGL((replay_kernel<false>), dim3(c->nq), dim3(64), lds, c->stream, c->d_cnt, ppad, c->d_rt, c->d_tr, nonn_tile0, r_begin, r_end, ord_base, c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k);
   } else {
-    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_mp[0], c->d_rtb[0]);
+    int rc = launch_scan2(c, tiles, (tiles == c->d_db ? c->d_db_tot : c->d_batch_tot) + tile_first * 64, tile_first, n_tiles, c->d_cnt2, ppad, bytes, nullptr, c->d_tmin[0], r_begin, r_end, c->d_rtb[0]);
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rtb[0], c->d_cp, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
                                     c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[0] : (const int2 *)nullptr, \
-                                    c->scan_variant == 2 ? c->d_mp[0] : (const int *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
+                                    c->scan_variant == 2 ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare, c->d_thr)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -508,6 +535,23 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
   return 0;
 }
 
+// thresholds the scans filter their output by, recomputed from the heaps in memory for queries [q0, q1): after a reset or an import
+int refresh_thresholds(uvaia_gpu_ctx *c, int q0, int q1)
+{
+  if (q1 <= q0) return 0;
+  if (q1 > c->nq) {     // padding rows of the last super-tile: permissive for ever
+    std::vector<int2> open_((size_t)(q1 - std::max(q0, c->nq)), make_int2(0x7fffffff, (int)0x80000000));
+    HIPCHK(c, hipMemcpyAsync(c->d_thr + std::max(q0, c->nq), open_.data(), open_.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    q1 = c->nq;
+    if (q1 <= q0) return 0;
+  }
+  if (c->acgt) hipLaunchKernelGGL((thresholds_kernel<true>), dim3(q1 - q0), dim3(64), 0, c->stream, c->d_heap, c->d_n, c->k, q0, c->d_thr);
+  else         hipLaunchKernelGGL((thresholds_kernel<false>), dim3(q1 - q0), dim3(64), 0, c->stream, c->d_heap, c->d_n, c->k, q0, c->d_thr);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -523,13 +567,13 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_thr, c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_pmask, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (int i = 0; i < 2; i++) if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
-  for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_mp[i]) hipFree(c->d_mp[i]); if (c->d_rtb[i]) hipFree(c->d_rtb[i]); }
+  for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_rtb[i]) hipFree(c->d_rtb[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
   for (int i_ = 0; i_ < 3; i_++) if (c->derive_streams[i_]) { hipStreamSynchronize(c->derive_streams[i_]); hipStreamDestroy(c->derive_streams[i_]); }
   for (auto &d : c->derive_chunks) hipEventDestroy(d.done);
@@ -697,6 +741,9 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
       for (int w = 0; w < Wp; w++) { c->NP += __builtin_popcount(cls[(size_t)w * 4 + 3]); c->NR += __builtin_popcount(rmask[(size_t)w]); }
       c->NP4 = ((c->NP + 31) / 32 + 3) / 4;
       c->NR4 = ((c->NR + 31) / 32 + 3) / 4;
+      // the compressed scan keeps a pair's deficit in 16 bits around SCAN3_BIAS: what the polymorphic and the rare columns can take away
+      // has to stay below it (16 000 such columns of at most 49 000: no SARS-CoV-2 query set comes near); else the packed-plane scan
+      if (c->scan_variant == 2 && (size_t)c->NP4 * 128 + (size_t)c->NR4 * 128 > SCAN3_BIAS - 256) c->scan_variant = 0;
       struct RareWord { int word; uint32_t m, l, h; };                  // one query's minority sites in one compressed word of the rare columns
       std::vector<std::vector<RareWord>> rare_q((size_t)c->nq_pad);
       std::vector<uint32_t> qrare((size_t)c->nq * std::max(c->NR4, 1) * 12, 0u);
@@ -859,6 +906,11 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     std::vector<uint32_t> pmask((size_t)c->W4 * 4, 0u);
     for (int sidx = lo; sidx < hi; sidx++) if (in_p[(size_t)sidx]) pmask[(size_t)sidx >> 5] |= 1u << (sidx & 31);
     OPENCHK(hipMalloc(&c->d_pmask, pmask.size() * 4)); OPENCHK(hipMemcpy(c->d_pmask, pmask.data(), pmask.size() * 4, hipMemcpyHostToDevice));
+    std::vector<int> cols;
+    for (int sidx = lo; sidx < hi; sidx++) if (in_p[(size_t)sidx]) cols.push_back(sidx);
+    c->n_idx = (int)cols.size(); c->NG4 = std::max(1, ((c->n_idx + 31) / 32 + 3) / 4);
+    cols.resize(cols.size() + 1, 0);
+    OPENCHK(hipMalloc(&c->d_idx_cols, cols.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_idx_cols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   OPENCHK(hipMalloc(&c->d_cp, cp.size() * 4)); OPENCHK(hipMemcpy(c->d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
   OPENCHK(hipMalloc(&c->d_cpm, cpm.size() * 4)); OPENCHK(hipMemcpy(c->d_cpm, cpm.data(), cpm.size() * 4, hipMemcpyHostToDevice));
@@ -873,11 +925,11 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   // ---- batch buffers
   // (the buffers of a streamed batch -- packed tiles, their derived planes, side rows: 25 KB per reference of max_pool -- are allocated
   // by the first call that streams sequences in: ensure_batch_buffers)
-  if (!c->fullscan) { OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(int2))); c->slice_cap[0] = (size_t)c->nq_pad * c->pool_pad; }
+  if (!c->fullscan) { OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(uint32_t))); c->slice_cap[0] = (size_t)c->nq_pad * c->pool_pad; }
+  OPENCHK(hipMalloc(&c->d_thr, (size_t)c->nq_pad * sizeof(int2)));
   OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   OPENCHK(hipMalloc(&c->d_rtb[0], c->pool_pad * sizeof(int4)));
   OPENCHK(hipMemset(c->d_rtb[0], 0, c->pool_pad * sizeof(int4)));
-  if (c->acgt && !c->fullscan && c->scan_variant == 2) OPENCHK(hipMalloc(&c->d_mp[0], (size_t)c->nq_pad * c->pool_pad * sizeof(int)));
   OPENCHK(hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
   OPENCHK(hipMalloc(&c->d_rt, c->pool_pad * sizeof(int4)));
@@ -917,6 +969,10 @@ int uvaia_gpu_reset(uvaia_gpu_ctx *c)
   hipLaunchKernelGGL(init_state_kernel, dim3((c->nq + 255) / 256), dim3(256), 0, c->stream, c->d_T, c->d_n, c->nq, c->nchar);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->d_snap, &c->nchar, sizeof(int), hipMemcpyHostToDevice, c->stream));   // cq->max_incompatible = n_sites (src/nearest.c:375)
+  {  // empty heaps take anything: the scans write every tile until a replay publishes thresholds again (scans of the previous search are
+     // waited for below before any new one can start, so no scan mixes the two)
+    int rc_ = refresh_thresholds(c, 0, c->nq_pad); if (rc_) return rc_;
+  }
   if (c->d_entered && c->db_n) HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
   for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1458,6 +1514,7 @@ int uvaia_gpu_state_import_range(uvaia_gpu_ctx *c, const void *src, int q0, int 
     HIPCHK(c, hipMemcpyAsync(c->d_T + q0, d + 4 + nqr, nqr * sizeof(int), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_heap + (size_t)q0 * he, d + 4 + 2 * nqr, nqr * he * sizeof(int), hipMemcpyDefault, c->stream));
   }
+  { int rc_ = refresh_thresholds(c, q0, q1); if (rc_) return rc_; }   // an imported state may be EARLIER than the one held (another search): recompute, never keep
   HIPCHK(c, hipStreamSynchronize(c->stream));     // src may be reused or freed once this returns
   return 0;
 }
@@ -1483,15 +1540,14 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
       for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       const size_t cap = std::max(need, (size_t)c->nq_pad * c->pool_pad);
-      int2 *&cb = buf ? c->d_cntb[buf] : c->d_cnt2;
-      if (cap > c->slice_cap[buf] || !cb) { if (cb) hipFree(cb); cb = nullptr; HIPCHK(c, hipMalloc(&cb, cap * sizeof(int2))); }
+      uint32_t *&cb = buf ? c->d_cntb[buf] : c->d_cnt2;
+      if (cap > c->slice_cap[buf] || !cb) { if (cb) hipFree(cb); cb = nullptr; HIPCHK(c, hipMalloc(&cb, cap * sizeof(uint32_t))); }
       if (c->d_tmin[buf]) hipFree(c->d_tmin[buf]);
       c->d_tmin[buf] = nullptr;
       HIPCHK(c, hipMalloc(&c->d_tmin[buf], (cap / 64) * sizeof(int2)));
       if (c->d_rtb[buf]) hipFree(c->d_rtb[buf]);
       c->d_rtb[buf] = nullptr;
       HIPCHK(c, hipMalloc(&c->d_rtb[buf], (std::max(cap / (size_t)c->nq_pad, ppad_) + 64) * sizeof(int4)));
-      if (c->d_mp[0] || (c->acgt && c->scan_variant == 2)) { if (c->d_mp[buf]) hipFree(c->d_mp[buf]); c->d_mp[buf] = nullptr; HIPCHK(c, hipMalloc(&c->d_mp[buf], cap * sizeof(int))); }
       c->slice_cap[buf] = cap;
     }
   }
@@ -1507,7 +1563,7 @@ int uvaia_gpu_slice_scan(uvaia_gpu_ctx *c, size_t first, size_t n, int buf)
   c->slice_rb[buf] = (int)(first - (size_t)tf * 64); c->slice_re[buf] = c->slice_rb[buf] + (int)n;
   c->slice_scanned[buf] = true; c->slice_cons_done[buf] = false;
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, ss, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_mp[buf], c->d_rtb[buf]);
+  int rc = launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, buf ? c->d_cntb[buf] : c->d_cnt2, n_tiles * 64, bytes, ss, c->d_tmin[buf], c->slice_rb[buf], c->slice_re[buf], c->d_rtb[buf]);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->scan_done[buf], ss));
   return 0;
@@ -1529,12 +1585,12 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   const int ppad = n_tiles * 64;
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   const int lq_words = (c->replay_lq && !c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
-  const int2 *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
+  const uint32_t *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2P(A, B, PF_) hipLaunchKernelGGL((replay2_kernel<A, B, PF_>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
-                                  (c->scan_variant == 2 && c->shard_world == 1) ? c->d_mp[buf] : (const int *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
+                                  (c->scan_variant == 2 && c->shard_world == 1) ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare, c->d_thr)
   // Candidates of a tile whose on-demand counters are requested ahead.  The bookkeeping of the request slots costs more than the
   // latency it hides (measured on one box: config[1] 3.69 / 3.54 / 3.60 ms per step with 3 / 2 / 1, 4 queries x 1 M references
   // 4.37 / 4.03 / 3.89; with 6 or 8 over 7 ms): two for large query sets, one -- request, then use -- for a handful of queries.
@@ -1627,7 +1683,7 @@ int uvaia_gpu_shard_scan(uvaia_gpu_ctx *c, size_t first, size_t n, void *cnt, vo
   }
   const int rb = (int)(first - (size_t)tf * 64);
   const double bytes = (double)n * (double)c->W4 * 16.0 * c->P + (double)c->nq * (double)c->W4 * 16.0 * c->P;
-  return launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, (int2 *)cnt, n_tiles * 64, bytes, ss, (int2 *)tmin, rb, rb + (int)n, c->d_mp[0], c->d_rtb[0]);
+  return launch_scan2(c, c->d_db, c->d_db_tot + tf * 64, tf, n_tiles, (uint32_t *)cnt, n_tiles * 64, bytes, ss, (int2 *)tmin, rb, rb + (int)n, c->d_rtb[0]);
 }
 
 int uvaia_gpu_scan_wait(uvaia_gpu_ctx *c)
@@ -1676,13 +1732,14 @@ int uvaia_gpu_shard_replay(uvaia_gpu_ctx *c, const void *cnt, const void *tmin, 
   const size_t lds = (size_t)(c->k + 1) * HEAP_ENTRY * sizeof(int);
   const int lq_words = (c->replay_lq && !c->acgt && lds + (size_t)c->W4 * 4 * 6 * 4 + 128 <= 64 * 1024) ? c->W4 * 4 * 6 : 0;
   // the kernel indexes rows by query number: shift the bases so that row q0 is the buffer's first row
-  const int2 *cntp = (const int2 *)cnt - (ptrdiff_t)q0 * ppad, *tminp = (const int2 *)tmin - (ptrdiff_t)q0 * (ppad / 64);
+  const uint32_t *cntp = (const uint32_t *)cnt - (ptrdiff_t)q0 * ppad;
+  const int2 *tminp = (const int2 *)tmin - (ptrdiff_t)q0 * (ppad / 64);
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
   // --acgt: dist_unique of the pairs that reach a heap is counted from the packed planes (the scan's per-pair count stays on the scanning rank)
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cntp, ppad, c->d_rt, c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
-                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, tminp, (const int *)nullptr, lq_words, c->replay_prio, \
-                                  (const uint4 *)nullptr, c->NP4 + c->NR4, c->NP4, 0, (const uint32_t *)nullptr)
+                                  c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, tminp, (const uint32_t *)nullptr, lq_words, c->replay_prio, \
+                                  (const uint4 *)nullptr, c->NP4 + c->NR4, c->NP4, 0, (const uint32_t *)nullptr, c->d_thr)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -1699,7 +1756,8 @@ struct uvaia_gpu_group {
   std::vector<uvaia_gpu_ctx *> ctx;
   std::vector<int> q0, q1;                      // query shard of each member (multiples of 16)
   struct Member {
-    int2 *send_cnt[2] = {}, *send_tmin[2] = {}, *recv_cnt[2] = {}, *recv_tmin[2] = {};
+    uint32_t *send_cnt[2] = {}, *recv_cnt[2] = {};
+    int2 *send_tmin[2] = {}, *recv_tmin[2] = {};
     hipStream_t copy = nullptr;
     hipEvent_t scanned[2] = {}, fetched[2] = {}, replayed[2] = {};    // scan into send[b] done; this member's copies out of everyone's send[b] done; replays from recv[b] done
     bool fetched_rec[2] = {}, replayed_rec[2] = {};
@@ -1777,9 +1835,9 @@ int uvaia_gpu_group_open(uvaia_gpu_group **out, const uvaia_gpu_query *q, int he
       hipError_t e = hipSetDevice(g->ctx[(size_t)i]->device);
       if (e == hipSuccess) e = hipStreamCreateWithFlags(&mm.copy, hipStreamNonBlocking);
       for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipMalloc(&mm.send_cnt[b], (size_t)g->rows * pcols * sizeof(int2));
+        e = hipMalloc(&mm.send_cnt[b], (size_t)g->rows * pcols * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&mm.send_tmin[b], (size_t)g->rows * (pcols / 64) * sizeof(int2));
-        if (e == hipSuccess) e = hipMalloc(&mm.recv_cnt[b], (size_t)g->n * myrows * pcols * sizeof(int2));
+        if (e == hipSuccess) e = hipMalloc(&mm.recv_cnt[b], (size_t)g->n * myrows * pcols * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&mm.recv_tmin[b], (size_t)g->n * myrows * (pcols / 64) * sizeof(int2));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&mm.scanned[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&mm.fetched[b], hipEventDisableTiming);
@@ -1870,7 +1928,7 @@ int uvaia_gpu_group_search_resident(uvaia_gpu_group *g, size_t pool, int64_t ord
           const size_t tiles = (pc.first + pc.n + 63) / 64 - pc.first / 64, ppad = tiles * 64, slot = k - s0;
           GCHK(g, hipStreamWaitEvent(md.copy, mo.scanned[bsel], 0));
           GCHK(g, hipMemcpyPeerAsync(md.recv_cnt[bsel] + slot * myrows * (g->piece + 64), cd->device, mo.send_cnt[bsel] + (size_t)g->q0[(size_t)d] * ppad, g->ctx[(size_t)pc.owner]->device,
-                                     myrows * ppad * sizeof(int2), md.copy));
+                                     myrows * ppad * sizeof(uint32_t), md.copy));
           GCHK(g, hipMemcpyPeerAsync(md.recv_tmin[bsel] + slot * myrows * ((g->piece + 64) / 64), cd->device, mo.send_tmin[bsel] + (size_t)g->q0[(size_t)d] * tiles, g->ctx[(size_t)pc.owner]->device,
                                      myrows * tiles * sizeof(int2), md.copy));
         }
@@ -1958,30 +2016,33 @@ static int ball_range(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first
   HIPCHK(c, hipMemcpyAsync(&n_ask, c->d_ball_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ball_asked += (unsigned long long)n_ask;
-  // the references whose answer depends on the queries, max_pool at a time (the order of the list does not matter: every entry
-  // writes its own result)
-  for (int done = 0; done < n_ask;) {
-    const int m = std::min<int>(n_ask - done, (int)(c->pool_pad - 64)), mt = (m + 63) / 64, ppad = mt * 64;
-    const size_t tile_u4 = (size_t)c->W4 * c->P * 64;
+  // the references whose answer depends on the queries: their planes on the columns of query->idx gathered into dense tiles, the pair
+  // scan on those, the reference's walk over the queries folded into it (kernels_ball.inc)
+  if (n_ask > 0) {
+    int rc = ensure_qgather(c); if (rc) return rc;
+    const int mt = (n_ask + 63) / 64;
+    const size_t tile_u4 = (size_t)c->NG4 * c->P * 64;
     if (c->ball_tiles_cap < (size_t)mt) {
       if (c->d_ball_tiles) hipFree(c->d_ball_tiles);
-      c->d_ball_tiles = nullptr;
-      HIPCHK(c, hipMalloc(&c->d_ball_tiles, (size_t)mt * tile_u4 * sizeof(uint4)));
-      c->ball_tiles_cap = (size_t)mt;
+      if (c->d_ball_key) hipFree(c->d_ball_key);
+      c->d_ball_tiles = nullptr; c->d_ball_key = nullptr; c->ball_tiles_cap = 0;
+      const size_t cap = (size_t)mt + (size_t)mt / 4 + 16;
+      HIPCHK(c, hipMalloc(&c->d_ball_tiles, cap * tile_u4 * sizeof(uint4)));
+      HIPCHK(c, hipMalloc(&c->d_ball_key, cap * 64 * sizeof(unsigned long long)));
+      c->ball_tiles_cap = cap;
     }
-    if (c->acgt) hipLaunchKernelGGL((gather_refs_kernel<3>), dim3(mt), dim3(256), 0, c->stream, tiles, tile_first, c->W4, c->d_ball_list + done, m, c->d_ball_tiles);
-    else         hipLaunchKernelGGL((gather_refs_kernel<4>), dim3(mt), dim3(256), 0, c->stream, tiles, tile_first, c->W4, c->d_ball_list + done, m, c->d_ball_tiles);
+    HIPCHK(c, hipMemsetAsync(c->d_ball_key, 0xFF, (size_t)mt * 64 * sizeof(unsigned long long), c->stream));
+    if (c->acgt) hipLaunchKernelGGL((ball_gather_cols_kernel<3>), dim3(mt), dim3(64), 0, c->stream, tiles, tile_first, c->W4, c->d_pmask, c->d_ball_list, n_ask, c->NG4, c->d_ball_tiles);
+    else         hipLaunchKernelGGL((ball_gather_cols_kernel<4>), dim3(mt), dim3(64), 0, c->stream, tiles, tile_first, c->W4, c->d_pmask, c->d_ball_list, n_ask, c->NG4, c->d_ball_tiles);
     HIPCHK(c, hipGetLastError());
-    int rc = ensure_cnt4(c, (size_t)c->nq_pad * c->pool_pad); if (rc) return rc;
-    const bool prof = c->profile; c->profile = false;     // not the nearest-neighbour scan the statistics describe
-    rc = ensure_qpoly(c); if (rc) return rc;
-    rc = launch_scan(c, c->d_ball_tiles, 0, mt, c->d_qpoly, c->nq, c->d_cnt, ppad, 0.0);
-    c->profile = prof;
-    if (rc) return rc;
-    if (c->acgt) hipLaunchKernelGGL((ball_finish_kernel<true>), dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_cnt, ppad, c->nq, c->d_ball_list + done, c->d_ball_cdist + done, m, radius, r_lo, c->d_mindist);
-    else         hipLaunchKernelGGL((ball_finish_kernel<false>), dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_cnt, ppad, c->nq, c->d_ball_list + done, c->d_ball_cdist + done, m, radius, r_lo, c->d_mindist);
+    constexpr int QTB = 16;
+    const int n_qtiles = (c->nq + QTB - 1) / QTB;
+    dim3 grid(scan_grid_size(n_qtiles, (mt + 3) / 4));
+    if (c->acgt) hipLaunchKernelGGL((ball_scan_kernel<true, QTB>), grid, dim3(256), 0, c->stream, c->d_ball_tiles, mt, c->NG4, c->d_qg, c->nq, n_qtiles, c->d_ball_cdist, n_ask, radius, c->d_ball_key);
+    else         hipLaunchKernelGGL((ball_scan_kernel<false, QTB>), grid, dim3(256), 0, c->stream, c->d_ball_tiles, mt, c->NG4, c->d_qg, c->nq, n_qtiles, c->d_ball_cdist, n_ask, radius, c->d_ball_key);
     HIPCHK(c, hipGetLastError());
-    done += m;
+    hipLaunchKernelGGL(ball_finish2_kernel, dim3((n_ask + 255) / 256), dim3(256), 0, c->stream, c->d_ball_key, c->d_ball_list, c->d_ball_cdist, n_ask, radius, r_lo, c->d_mindist);
+    HIPCHK(c, hipGetLastError());
   }
   if (mindist_host) HIPCHK(c, hipMemcpyAsync(mindist_host, c->d_mindist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -93,9 +93,9 @@ class TorchExchange:
         cols = plan.piece + 64                                    # a piece cut by a batch boundary may start inside a tile
         my = max(1, plan.q1 - plan.q0)
         mk = lambda n: torch.empty(n, dtype=torch.int32, device=device, pin_memory=(pinned and device == "cpu"))
-        self.send_cnt = [mk(rows * cols * 2) for _ in range(2)]
+        self.send_cnt = [mk(rows * cols) for _ in range(2)]            # one dword per pair: first counter | second << 16
         self.send_tmin = [mk(rows * (cols // 64) * 2) for _ in range(2)]
-        self.recv_cnt = [mk(plan.world * my * cols * 2) for _ in range(2)]
+        self.recv_cnt = [mk(plan.world * my * cols) for _ in range(2)]
         self.recv_tmin = [mk(plan.world * my * (cols // 64) * 2) for _ in range(2)]
         self.maxbuf = torch.zeros(1, dtype=torch.int32, device=device)
         if device != "cpu":
@@ -113,7 +113,7 @@ class TorchExchange:
         mine = [p for p in stripe if p.owner == plan.rank]
         my = plan.q1 - plan.q0
         where = []
-        for what, ints_per_col, send, recv in (("cnt", 2 * 64, self.send_cnt[b], self.recv_cnt[b]), ("tmin", 2, self.send_tmin[b], self.recv_tmin[b])):
+        for what, ints_per_col, send, recv in (("cnt", 64, self.send_cnt[b], self.recv_cnt[b]), ("tmin", 2, self.send_tmin[b], self.recv_tmin[b])):
             # input: for destination d the rows [q0_d, q1_d) of this rank's piece -- contiguous in the scan's output, in rank order
             t_me = mine[0].tiles if mine else 0
             in_split = [(q1 - q0) * t_me * ints_per_col for q0, q1 in plan.shards]

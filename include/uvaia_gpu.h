@@ -76,7 +76,7 @@ typedef struct {
   int rare_max;                /* a polymorphic column counts as "rare" when all but at most this many queries carry the same base; -1 = no rare columns */
   int scan;                    /* UVAIA_GPU_SCAN_* */
   int serial;                  /* 1 = no overlap between the rebuild of the derived planes, the scans and the replays (isolated kernel timings) */
-  int scan_tiles_per_wave;     /* column-compressed scan: 1 or 2 tiles of 64 references per wave (default 2) */
+  int scan_tiles_per_wave;     /* column-compressed scan: 1, 2 or 4 tiles of 64 references per wave (default 2; 4 only with 8 waves per block) */
   int scan_waves_per_block;    /* column-compressed scan: 4 or 8 waves share a super-tile of 64 queries (default 8) */
   int rederive_streams;        /* uvaia_gpu_db_rederive: its chunks alternate over 1..3 streams (default 3: all chunks in flight at once, the first still done first) */
   int reserved[7];             /* zero */

@@ -115,3 +115,23 @@ def test_tolerance_range_may_start_anywhere_under_reference_shards(data):
         eng.set_active_queries(16, 24)
         assert isinstance(eng.max_tolerance(), int)
         eng.set_active_queries(0, 24)
+
+
+def test_bench_two_ranks_over_gloo_on_one_card_end_to_end():
+    """`bench.py --gpus 2` as the driver launches it for N > 1 (it starts its own ranks when no launcher did), rehearsed on one card
+    with the exchange over gloo (UVAIA_BENCH_BACKEND): the JSON line must be a two-rank line and the sample that went through the
+    reference-shard protocol of the timed step must equal the oracle on every rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UVAIA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "200", "--refs", "8192", "--nbest", "20"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["parity_check_on_timed_path"] is True
+    assert out["value"] > 0 and "reference shards" in out["multi_gpu"]

@@ -381,8 +381,9 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
 #define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, c->d_thr, cons ? 0 : 1, st_first)
 #define SCAN3_NW(A, RR) { if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR); else SCAN3_LAUNCH(4, A, RR); }
-    if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
-    else        { if (c->acgt) SCAN3_NW(true, 1) else SCAN3_NW(false, 1) }
+    if (R == 4)      { if (c->acgt) SCAN3_LAUNCH(8, true, 4); else SCAN3_LAUNCH(8, false, 4); }     // four tiles per wave: eight waves only (open_tuned)
+    else if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
+    else             { if (c->acgt) SCAN3_NW(true, 1) else SCAN3_NW(false, 1) }
 #undef SCAN3_NW
 #undef SCAN3_LAUNCH
     HIPCHK(c, hipGetLastError());
@@ -592,7 +593,7 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   uvaia_gpu_tuning tn;
   memset(&tn, 0, sizeof tn);
   if (tune) tn = *tune;
-  if (tn.scan < 0 || tn.scan > UVAIA_GPU_SCAN_WIDE || (tn.scan_tiles_per_wave != 0 && tn.scan_tiles_per_wave != 1 && tn.scan_tiles_per_wave != 2) ||
+  if (tn.scan < 0 || tn.scan > UVAIA_GPU_SCAN_WIDE || (tn.scan_tiles_per_wave != 0 && tn.scan_tiles_per_wave != 1 && tn.scan_tiles_per_wave != 2 && tn.scan_tiles_per_wave != 4) ||
       (tn.scan_waves_per_block != 0 && tn.scan_waves_per_block != 4 && tn.scan_waves_per_block != 8) || (tn.subslice_refs != 0 && tn.subslice_refs < 64))
     return fail(nullptr, UVAIA_GPU_EINVAL, "bad tuning values");
   if (!out) return fail(nullptr, UVAIA_GPU_EINVAL, "ctx is NULL");
@@ -621,6 +622,7 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   c->serial = tn.serial != 0;
   if (tn.scan_tiles_per_wave) c->scan_R = tn.scan_tiles_per_wave;
   if (tn.scan_waves_per_block) c->scan_NW = tn.scan_waves_per_block;
+  if (c->scan_R == 4 && c->scan_NW != 8) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "four reference tiles per wave go with eight waves per block"); }
   if (tn.subslice_refs) { c->subslice = tn.subslice_refs; c->subslice_forced = true; }
   if (tn.rederive_streams >= 1 && tn.rederive_streams <= 3) c->derive_nstreams = tn.rederive_streams;
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the

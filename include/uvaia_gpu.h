@@ -213,9 +213,7 @@ int uvaia_gpu_search_resident_pool (uvaia_gpu_ctx *ctx, size_t first, size_t n, 
  * set_shard: before the database is reserved.  shard_scan: references [first, first+n) inside ONE owned piece, n <= max_pool;
  *   cnt  uint32 [uvaia_gpu_shard_rows()][tiles * 64] pair counters as the scan kernels write them (first | second << 16: ACGT matches and
  *                                                    valid pairs, with --acgt mismatches and comparable sites), row = query, a reference
- *                                                    in column (position - 64 * (first / 64)); tiles = tiles the range touches.  A tile
- *                                                    of 64 counters is only written when its bounds pass the thresholds this context
- *                                                    holds for the query (permissive for queries it does not replay itself)
+ *                                                    in column (position - 64 * (first / 64)); tiles = tiles the range touches
  *   tmin int2 [uvaia_gpu_shard_rows()][tiles]        the two bounds per (query, tile) the replay skips tiles by
  *   both caller-owned device buffers; asynchronous on the scan stream, uvaia_gpu_scan_wait() returns when they are complete.
  * shard_replay: gate + heaps of queries [q0, q1) over references [first, first+n) (any rank's piece) from buffers of the same

@@ -123,8 +123,7 @@ struct uvaia_gpu_ctx {
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
-  uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 (written for the tiles that can still admit something)
-  int2 *d_thr = nullptr;         // [nq_pad] per query {largest mismatch count held + 1, first key of the worst kept entry}: what the scans filter their output by
+  uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 
   unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
   bool fullscan = false;         // four-counter scan + the replay over it (alignments above 49 000 columns; tuning.scan = UVAIA_GPU_SCAN_WIDE)
   size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
@@ -134,6 +133,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_pmask = nullptr;   // [W4*4] mask of the polymorphic query columns (query->idx)
   int *d_mindist = nullptr, *d_ball_list = nullptr, *d_ball_cdist = nullptr, *d_ball_n = nullptr; size_t ball_cap = 0;   // radius search: results, the references that go on to the queries
   uint4 *d_ball_tiles = nullptr; size_t ball_tiles_cap = 0; unsigned long long ball_asked = 0;
+  int ball_split[10] = {};                                  // ball_gather_cols_kernel: word groups and gathered columns before each of its four waves
   int *d_idx_cols = nullptr; int n_idx = 0, NG4 = 0;       // query->idx (the polymorphic query columns) and the word groups they fill once gathered
   uint32_t *d_qg = nullptr;                                 // the queries on those columns (kernels_ball.inc), built by the first radius search
   unsigned long long *d_ball_key = nullptr;                 // per listed reference: first query that ends the reference's loop (query << 32 | distance)
@@ -379,7 +379,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     const int st_first = c->act_q0 / QS, n_st = (c->act_q1 + QS - 1) / QS - st_first;
     const int R = c->scan_R;
     dim3 grid3(scan_grid_size(n_st, (n_tiles + R - 1) / R));
-#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, c->d_thr, cons ? 0 : 1, st_first)
+#define SCAN3_LAUNCH(NWW, A, RR) hipLaunchKernelGGL((scan3_kernel<NWW, A, RR>), grid3, dim3(64 * NWW), 0, stream, ev, poly, tile_first, n_tiles, c->W4, c->NP4, c->NP4 + c->NR4, c->d_qpl, c->d_stream, c->d_sdir, grp, tote, tot_tile0, out, ppad, n_st, tmin, r_lo, r_hi, st_first)
 #define SCAN3_NW(A, RR) { if (c->scan_NW == 8) SCAN3_LAUNCH(8, A, RR); else SCAN3_LAUNCH(4, A, RR); }
     if (R == 4)      { if (c->acgt) SCAN3_LAUNCH(8, true, 4); else SCAN3_LAUNCH(8, false, 4); }     // four tiles per wave: eight waves only (open_tuned)
     else if (R == 2) { if (c->acgt) SCAN3_NW(true, 2) else SCAN3_NW(false, 2) }
@@ -392,7 +392,7 @@ int launch_scan2(uvaia_gpu_ctx *c, const uint4 *tiles, const int *tot_tile0, lon
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-#define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt, c->d_thr)
+#define LAUNCH(K, QT, CN) hipLaunchKernelGGL((K<QT, CN>), grid, block, 0, stream, tiles, tile_first, n_tiles, c->W4, qp, out, ppad, n_qtiles, tot_tile0, tmin, r_lo, r_hi, c->d_cp, rt)
 #define LAUNCH_QT(K, CN) switch (qt2) { case 1: LAUNCH(K, 1, CN); break; case 2: LAUNCH(K, 2, CN); break; case 4: LAUNCH(K, 4, CN); break; case 8: LAUNCH(K, 8, CN); break; default: LAUNCH(K, 16, CN); }
   if (c->acgt) { if (cons) { LAUNCH_QT(scan2_acgt_kernel, true) } else { LAUNCH_QT(scan2_acgt_kernel, false) } }
   else         { if (cons) { LAUNCH_QT(scan2_iupac_kernel, true) } else { LAUNCH_QT(scan2_iupac_kernel, false) } }
@@ -453,7 +453,7 @@ int run_batch(uvaia_gpu_ctx *c, const uint4 *tiles, const int *nonn_tile0, const
     if (rc) return rc;
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(c->nq), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, c->d_cnt2, ppad, c->d_rtb[0], c->d_cp, nonn_tile0, amb_tile0, r_begin, r_end, ord_base, \
                                     c->d_heap, c->d_n, c->d_T, c->d_snap, entered_tile0, c->k, tiles, tile_first, c->W4, c->d_qp, c->d_amb_q, c->d_stats, 0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[0] : (const int2 *)nullptr, \
-                                    c->scan_variant == 2 ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare, c->d_thr)
+                                    c->scan_variant == 2 ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, (tiles == c->d_db ? c->d_db_poly : c->d_batch_poly), c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
     if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
     else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -536,23 +536,6 @@ int pack_rows(uvaia_gpu_ctx *c, const char *const *seq, const char *rows, size_t
   return 0;
 }
 
-// thresholds the scans filter their output by, recomputed from the heaps in memory for queries [q0, q1): after a reset or an import
-int refresh_thresholds(uvaia_gpu_ctx *c, int q0, int q1)
-{
-  if (q1 <= q0) return 0;
-  if (q1 > c->nq) {     // padding rows of the last super-tile: permissive for ever
-    std::vector<int2> open_((size_t)(q1 - std::max(q0, c->nq)), make_int2(0x7fffffff, (int)0x80000000));
-    HIPCHK(c, hipMemcpyAsync(c->d_thr + std::max(q0, c->nq), open_.data(), open_.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    q1 = c->nq;
-    if (q1 <= q0) return 0;
-  }
-  if (c->acgt) hipLaunchKernelGGL((thresholds_kernel<true>), dim3(q1 - q0), dim3(64), 0, c->stream, c->d_heap, c->d_n, c->k, q0, c->d_thr);
-  else         hipLaunchKernelGGL((thresholds_kernel<false>), dim3(q1 - q0), dim3(64), 0, c->stream, c->d_heap, c->d_n, c->k, q0, c->d_thr);
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -568,7 +551,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_thr, c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_pmask, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
@@ -911,6 +894,12 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     std::vector<int> cols;
     for (int sidx = lo; sidx < hi; sidx++) if (in_p[(size_t)sidx]) cols.push_back(sidx);
     c->n_idx = (int)cols.size(); c->NG4 = std::max(1, ((c->n_idx + 31) / 32 + 3) / 4);
+    for (int v = 0; v <= 4; v++) {      // four shares of about the same number of columns, cut at word groups
+      int g = 0, bits = 0;
+      const int goal = (int)((long long)c->n_idx * v / 4);
+      while (g < c->W4 && (v == 4 || bits < goal)) { for (int j = 0; j < 4; j++) bits += __builtin_popcount(pmask[(size_t)g * 4 + j]); g++; }
+      c->ball_split[v] = v == 0 ? 0 : g; c->ball_split[5 + v] = v == 0 ? 0 : bits;
+    }
     cols.resize(cols.size() + 1, 0);
     OPENCHK(hipMalloc(&c->d_idx_cols, cols.size() * sizeof(int))); OPENCHK(hipMemcpy(c->d_idx_cols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
   }
@@ -928,7 +917,6 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   // (the buffers of a streamed batch -- packed tiles, their derived planes, side rows: 25 KB per reference of max_pool -- are allocated
   // by the first call that streams sequences in: ensure_batch_buffers)
   if (!c->fullscan) { OPENCHK(hipMalloc(&c->d_cnt2, (size_t)c->nq_pad * c->pool_pad * sizeof(uint32_t))); c->slice_cap[0] = (size_t)c->nq_pad * c->pool_pad; }
-  OPENCHK(hipMalloc(&c->d_thr, (size_t)c->nq_pad * sizeof(int2)));
   OPENCHK(hipMalloc(&c->d_tmin[0], (size_t)c->nq_pad * (c->pool_pad / 64) * sizeof(int2)));
   OPENCHK(hipMalloc(&c->d_rtb[0], c->pool_pad * sizeof(int4)));
   OPENCHK(hipMemset(c->d_rtb[0], 0, c->pool_pad * sizeof(int4)));
@@ -971,10 +959,6 @@ int uvaia_gpu_reset(uvaia_gpu_ctx *c)
   hipLaunchKernelGGL(init_state_kernel, dim3((c->nq + 255) / 256), dim3(256), 0, c->stream, c->d_T, c->d_n, c->nq, c->nchar);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->d_snap, &c->nchar, sizeof(int), hipMemcpyHostToDevice, c->stream));   // cq->max_incompatible = n_sites (src/nearest.c:375)
-  {  // empty heaps take anything: the scans write every tile until a replay publishes thresholds again (scans of the previous search are
-     // waited for below before any new one can start, so no scan mixes the two)
-    int rc_ = refresh_thresholds(c, 0, c->nq_pad); if (rc_) return rc_;
-  }
   if (c->d_entered && c->db_n) HIPCHK(c, hipMemsetAsync(c->d_entered, 0, ((c->db_n + 63) / 64) * 64, c->stream));
   for (int i_ = 0; i_ < 3; i_++) if (c->scan_streams[i_]) HIPCHK(c, hipStreamSynchronize(c->scan_streams[i_]));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1472,7 +1456,7 @@ int uvaia_gpu_replay_stats(uvaia_gpu_ctx *c, unsigned long long out[3], int rese
 {
   if (!c || !out) return UVAIA_GPU_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  unsigned long long h[4] = {0, 0, 0, 0};
+  unsigned long long h[3] = {0, 0, 0};
   HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
   if (reset) HIPCHK(c, hipMemset(c->d_stats, 0, sizeof h));
@@ -1516,7 +1500,6 @@ int uvaia_gpu_state_import_range(uvaia_gpu_ctx *c, const void *src, int q0, int 
     HIPCHK(c, hipMemcpyAsync(c->d_T + q0, d + 4 + nqr, nqr * sizeof(int), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_heap + (size_t)q0 * he, d + 4 + 2 * nqr, nqr * he * sizeof(int), hipMemcpyDefault, c->stream));
   }
-  { int rc_ = refresh_thresholds(c, q0, q1); if (rc_) return rc_; }   // an imported state may be EARLIER than the one held (another search): recompute, never keep
   HIPCHK(c, hipStreamSynchronize(c->stream));     // src may be reused or freed once this returns
   return 0;
 }
@@ -1592,7 +1575,7 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   uint8_t *ent = c->d_entered + tf * 64;
 #define REPLAY2P(A, B, PF_) hipLaunchKernelGGL((replay2_kernel<A, B, PF_>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
-                                  (c->scan_variant == 2 && c->shard_world == 1) ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare, c->d_thr)
+                                  (c->scan_variant == 2 && c->shard_world == 1) ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
   // Candidates of a tile whose on-demand counters are requested ahead.  The bookkeeping of the request slots costs more than the
   // latency it hides (measured on one box: config[1] 3.69 / 3.54 / 3.60 ms per step with 3 / 2 / 1, 4 queries x 1 M references
   // 4.37 / 4.03 / 3.89; with 6 or 8 over 7 ms): two for large query sets, one -- request, then use -- for a handful of queries.
@@ -1741,7 +1724,7 @@ int uvaia_gpu_shard_replay(uvaia_gpu_ctx *c, const void *cnt, const void *tmin, 
   // --acgt: dist_unique of the pairs that reach a heap is counted from the packed planes (the scan's per-pair count stays on the scanning rank)
 #define REPLAY2(A, B) hipLaunchKernelGGL((replay2_kernel<A, B>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cntp, ppad, c->d_rt, c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, tminp, (const uint32_t *)nullptr, lq_words, c->replay_prio, \
-                                  (const uint4 *)nullptr, c->NP4 + c->NR4, c->NP4, 0, (const uint32_t *)nullptr, c->d_thr)
+                                  (const uint4 *)nullptr, c->NP4 + c->NR4, c->NP4, 0, (const uint32_t *)nullptr)
   if (c->acgt) { if (c->n_idx_c > 0) REPLAY2(true, true); else REPLAY2(true, false); }
   else         { if (c->n_idx_c > 0) REPLAY2(false, true); else REPLAY2(false, false); }
 #undef REPLAY2
@@ -2034,8 +2017,11 @@ static int ball_range(uvaia_gpu_ctx *c, const uint4 *tiles, long long tile_first
       c->ball_tiles_cap = cap;
     }
     HIPCHK(c, hipMemsetAsync(c->d_ball_key, 0xFF, (size_t)mt * 64 * sizeof(unsigned long long), c->stream));
-    if (c->acgt) hipLaunchKernelGGL((ball_gather_cols_kernel<3>), dim3(mt), dim3(64), 0, c->stream, tiles, tile_first, c->W4, c->d_pmask, c->d_ball_list, n_ask, c->NG4, c->d_ball_tiles);
-    else         hipLaunchKernelGGL((ball_gather_cols_kernel<4>), dim3(mt), dim3(64), 0, c->stream, tiles, tile_first, c->W4, c->d_pmask, c->d_ball_list, n_ask, c->NG4, c->d_ball_tiles);
+    HIPCHK(c, hipMemsetAsync(c->d_ball_tiles, 0, (size_t)mt * tile_u4 * sizeof(uint4), c->stream));
+    BallSplit sp;
+    for (int v = 0; v < 5; v++) { sp.w4[v] = c->ball_split[v]; sp.bit[v] = c->ball_split[5 + v]; }
+    if (c->acgt) hipLaunchKernelGGL((ball_gather_cols_kernel<3>), dim3(mt), dim3(256), 0, c->stream, tiles, tile_first, c->W4, c->d_pmask, c->d_ball_list, n_ask, c->NG4, c->d_ball_tiles, sp);
+    else         hipLaunchKernelGGL((ball_gather_cols_kernel<4>), dim3(mt), dim3(256), 0, c->stream, tiles, tile_first, c->W4, c->d_pmask, c->d_ball_list, n_ask, c->NG4, c->d_ball_tiles, sp);
     HIPCHK(c, hipGetLastError());
     constexpr int QTB = 16;
     const int n_qtiles = (c->nq + QTB - 1) / QTB;

@@ -79,7 +79,9 @@ typedef struct {
   int scan_tiles_per_wave;     /* column-compressed scan: 1, 2 or 4 tiles of 64 references per wave (default 2; 4 only with 8 waves per block) */
   int scan_waves_per_block;    /* column-compressed scan: 4 or 8 waves share a super-tile of 64 queries (default 8) */
   int rederive_streams;        /* uvaia_gpu_db_rederive: its chunks alternate over 1..3 streams (default 3: all chunks in flight at once, the first still done first) */
-  int reserved[7];             /* zero */
+  int replay_phases;           /* ordered replay: 1 = one kernel per slice (replay2_kernel), 2 = candidates in parallel + the ordered machine over their records
+                                  wherever that applies (the packed-plane scan); 0 = two phases up to 32 queries */
+  int reserved[6];             /* zero */
 } uvaia_gpu_tuning;
 int uvaia_gpu_open_tuned (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning /* may be NULL */);
 void uvaia_gpu_close (uvaia_gpu_ctx *ctx);
@@ -224,6 +226,17 @@ int uvaia_gpu_shard_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, void *cnt,
 int uvaia_gpu_scan_wait (uvaia_gpu_ctx *ctx);
 int uvaia_gpu_replay_wait (uvaia_gpu_ctx *ctx);      /* replays issued so far are complete: their counter buffers may be overwritten */
 int uvaia_gpu_set_snapshot (uvaia_gpu_ctx *ctx, int snapshot);
+/* Ordering against a stream the caller owns (a hipStream_t: the stream its collectives run on), by events, without the host: the
+ * reference-shard driver queues scan -> exchange -> replay of stripe after stripe and never blocks.
+ *   mark              remembers, under slot 0..7, the scans (or replays) issued so far
+ *   stream_wait_mark  `stream` waits for that mark (the scan whose output the exchange sends; the replays that still read a buffer the
+ *                     exchange is about to refill)
+ *   wait_stream       the scans (or replays) issued from now on wait for what `stream` holds now (the exchange still reading the buffer a
+ *                     scan overwrites; the exchange that delivers a replay's counters) */
+enum { UVAIA_GPU_SCANS = 0, UVAIA_GPU_REPLAYS = 1 };
+int uvaia_gpu_mark (uvaia_gpu_ctx *ctx, int what, int slot);
+int uvaia_gpu_stream_wait_mark (uvaia_gpu_ctx *ctx, void *stream, int slot);
+int uvaia_gpu_wait_stream (uvaia_gpu_ctx *ctx, int what, void *stream);
 int uvaia_gpu_shard_replay (uvaia_gpu_ctx *ctx, const void *cnt, const void *tmin, size_t first, size_t n, int64_t ordinal0, int q0, int q1);
 
 /* ---- a group of contexts driven by ONE host thread (the command line's --devices): the reference-shard protocol with peer copies

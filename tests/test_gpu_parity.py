@@ -532,3 +532,80 @@ def test_benchmark_shaped_data_push_and_resident(acgt):
             n, T, sc, od = e.drain()
             assert capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T
             assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+def _resident_search(q, refs, pool, nbest, tuning=None):
+    with capi.Engine.from_query(q, nbest=nbest, max_pool=pool, tuning=tuning) as eng:
+        eng.db_reserve(len(refs))
+        eng.db_append(refs)
+        out = []
+        for _ in range(2):                                   # a second search over the same resident database: same answer
+            eng.reset()
+            ent = eng.search_resident(pool)
+            n, T, sc, od = eng.drain()
+            out.append((capi.finalise_heaps(n, sc, od), list(T), ent))
+        assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+    return out[0]
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("phases", [1, 2])
+def test_two_phase_replay_of_few_queries_many_states(acgt, phases):
+    """A handful of queries over a resident database: candidates in parallel + the ordered machine over their records
+    (kernels_replay3.inc, the default up to 32 queries) and the one-kernel replay must both reproduce the oracle on many tiny
+    problems with heavy ties, tiny heaps and tiny pools (snapshots taken often: the cut pre-scores of src/nearest.c:431-432)."""
+    rng = np.random.default_rng(17)
+    for it in range(10):
+        L = int(rng.integers(40, 260))
+        refs, root, cols = F.synth_alignment(int(rng.integers(5, 400)), L, seed=300 + it, p_snp=0.02, p_amb=0.01)
+        qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=400 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)
+        q = O.Query(qs, _names(len(qs), "q"), acgt=acgt, ambig_q=1.0)
+        if q.ntax < 1:
+            continue
+        pool, nbest = int(rng.integers(1, 70)), int(rng.integers(1, 12))
+        gold = O.search(q, refs, _names(len(refs)), pool=pool, nbest=nbest, ambig_r=1.0)
+        rows, T, ent = _resident_search(q, refs, pool, nbest, tuning={"replay_phases": phases, "subslice_refs": int(rng.integers(64, 200))})
+        assert rows == [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows], (it, pool, nbest)
+        assert T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved), (it, pool, nbest)
+
+
+def test_two_phase_replay_reproduces_the_truncated_prescore():
+    """the quirk of test_truncated_consensus_prescore_is_reproduced through the resident path: the candidates' records are cut at the
+    batch snapshot exactly as cq->res would be, and a tolerance that rises above the snapshot inside the batch lets them in"""
+    L = 400
+    base = bytearray(b"A" * L)
+    q = O.Query([bytes(base)], ["q0"])
+
+    def ref_with(mism_sites, n_sites=()):
+        s = bytearray(base)
+        for i in mism_sites: s[i] = ord("C")
+        for i in n_sites: s[i] = ord("N")
+        return bytes(s)
+
+    refs = [ref_with(range(1, 11)), ref_with([20], n_sites=range(200, 400)), ref_with([]), ref_with([390, 395, 399])]
+    for pool in (2, 4):
+        gold = O.search(q, refs, _names(4), pool=pool, nbest=2, ambig_r=1.0)
+        for phases in (1, 2):
+            rows, T, _ = _resident_search(q, refs, pool, 2, tuning={"replay_phases": phases})
+            assert rows[0] == [(tuple(s), o) for o, _, s in gold.rows[0]], (pool, phases)
+            assert T == gold.final_T
+    gold = O.search(q, refs, _names(4), pool=2, nbest=2, ambig_r=1.0)
+    assert (394, 394, 394, 396, 0, 400) in [tuple(s) for _, _, s in gold.rows[0]]
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("nq", [3, 32, 70])
+def test_two_phase_replay_at_genome_length(acgt, nq):
+    """generator data at full length (N runs, ambiguity codes: the on-demand counters of the default mode), several sub-slices, pools
+    that matter when the query set has constant-and-complete columns (3 queries) and when it has none; 70 queries on the packed-plane
+    scan with the two phases forced"""
+    from uvaia_amd import hostlib
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, nq)
+    refs, _ = gen.generate_bytes(0, 3000)
+    refs = refs + qs[:2]
+    q = O.Query(qs, _names(nq, "q"), acgt=acgt)
+    gold = O.search(q, refs, _names(len(refs)), pool=700, nbest=25, ambig_r=0.5)
+    rows, T, ent = _resident_search(q, refs, 700, 25, tuning={"replay_phases": 2, "scan": "packed", "subslice_refs": 500})
+    assert rows == [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows]
+    assert T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)

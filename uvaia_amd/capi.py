@@ -22,6 +22,7 @@ SYMBOLS = [
     "uvaia_gpu_db_tile_bytes", "uvaia_gpu_db_side_row_ints", "uvaia_gpu_db_export", "uvaia_gpu_db_append_packed", "uvaia_gpu_db_clear", "uvaia_gpu_db_rederive",
     "uvaia_gpu_set_active_queries", "uvaia_gpu_max_tolerance", "uvaia_gpu_search_resident_pool",
     "uvaia_gpu_db_set_shard", "uvaia_gpu_shard_rows", "uvaia_gpu_shard_scan", "uvaia_gpu_scan_wait", "uvaia_gpu_replay_wait", "uvaia_gpu_set_snapshot", "uvaia_gpu_shard_replay",
+    "uvaia_gpu_mark", "uvaia_gpu_stream_wait_mark", "uvaia_gpu_wait_stream",
     "uvaia_gpu_group_open", "uvaia_gpu_group_close", "uvaia_gpu_group_last_error", "uvaia_gpu_group_size", "uvaia_gpu_group_member", "uvaia_gpu_group_query_shard",
     "uvaia_gpu_group_db_reserve", "uvaia_gpu_group_db_append", "uvaia_gpu_group_db_append_packed", "uvaia_gpu_group_db_clear", "uvaia_gpu_group_db_rederive",
     "uvaia_gpu_group_db_size", "uvaia_gpu_group_reset", "uvaia_gpu_group_search_resident", "uvaia_gpu_group_push", "uvaia_gpu_group_drain", "uvaia_gpu_group_sync",
@@ -37,7 +38,7 @@ class GpuError(RuntimeError):
 class Tuning(C.Structure):
     """uvaia_gpu_tuning: optional knobs of uvaia_gpu_open_tuned (0 = the library's choice); they change speed, never results."""
     _fields_ = [("subslice_refs", C.c_size_t), ("rare_max", C.c_int), ("scan", C.c_int), ("serial", C.c_int),
-                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("reserved", C.c_int * 7)]
+                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("replay_phases", C.c_int), ("reserved", C.c_int * 6)]
 
     SCAN = {"auto": 0, "packed": 1, "compressed": 2, "wide": 3}
 
@@ -146,6 +147,8 @@ def load_library():
         "uvaia_gpu_replay_wait": (C.c_int, [vp]),
         "uvaia_gpu_set_snapshot": (C.c_int, [vp, C.c_int]),
         "uvaia_gpu_shard_replay": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64, C.c_int, C.c_int]),
+        "uvaia_gpu_mark": (C.c_int, [vp, C.c_int, C.c_int]), "uvaia_gpu_stream_wait_mark": (C.c_int, [vp, C.c_void_p, C.c_int]),
+        "uvaia_gpu_wait_stream": (C.c_int, [vp, C.c_int, C.c_void_p]),
         "uvaia_gpu_group_open": (C.c_int, [C.POINTER(vp), C.POINTER(_Query), C.c_int, pi, C.c_int, C.c_size_t, C.c_size_t]),
         "uvaia_gpu_group_close": (None, [vp]),
         "uvaia_gpu_group_last_error": (C.c_char_p, [vp]),
@@ -315,6 +318,17 @@ class Engine:
 
     def set_snapshot(self, v):
         self._chk(self.L.uvaia_gpu_set_snapshot(self.ctx, int(v)))
+
+    SCANS, REPLAYS = 0, 1
+
+    def mark(self, what, slot):
+        self._chk(self.L.uvaia_gpu_mark(self.ctx, int(what), int(slot)))
+
+    def stream_wait_mark(self, stream, slot):
+        self._chk(self.L.uvaia_gpu_stream_wait_mark(self.ctx, C.c_void_p(stream), int(slot)))
+
+    def wait_stream(self, what, stream):
+        self._chk(self.L.uvaia_gpu_wait_stream(self.ctx, int(what), C.c_void_p(stream)))
 
     def shard_replay(self, cnt_ptr, tmin_ptr, first, n, ordinal0, q0, q1):
         self._chk(self.L.uvaia_gpu_shard_replay(self.ctx, C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr), int(first), int(n), int(ordinal0), int(q0), int(q1)))

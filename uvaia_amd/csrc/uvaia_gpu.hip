@@ -125,6 +125,12 @@ struct uvaia_gpu_ctx {
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
   uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 
   unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
+  // two-phase replay of a handful of queries (kernels_replay3.inc): per query the state the slice starts from, per (query, tile) the mask of
+  // the references that can still enter, per such reference its complete score vector
+  int *d_summary = nullptr; unsigned long long *d_cand_mask = nullptr; int4 *d_cand_rec = nullptr; size_t cand_tiles_cap = 0;
+  hipEvent_t order_ev[16] = {}; unsigned order_rr = 0;   // uvaia_gpu_wait_stream: ordering against a caller-owned stream
+  hipEvent_t mark_ev[8][3] = {}; bool mark_set[8][3] = {}; // uvaia_gpu_mark
+  int replay_phases = 0;         // 0 = by query count (two phases up to 32 queries on the packed-plane scan), 1 = always one kernel, 2 = two phases wherever they apply
   bool fullscan = false;         // four-counter scan + the replay over it (alignments above 49 000 columns; tuning.scan = UVAIA_GPU_SCAN_WIDE)
   size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
@@ -203,6 +209,7 @@ void fill_code_table(uint8_t *t)
 #include "kernels_scan_history.inc"
 #include "kernels_scan3.inc"
 #include "kernels_replay.inc"
+#include "kernels_replay3.inc"
 #include "kernels_ball.inc"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -551,12 +558,14 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_summary, c->d_cand_mask, c->d_cand_rec, c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_pmask, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (int i = 0; i < 2; i++) if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
+  for (int i = 0; i < 16; i++) if (c->order_ev[i]) hipEventDestroy(c->order_ev[i]);
+  for (int i = 0; i < 8; i++) for (int j = 0; j < 3; j++) if (c->mark_ev[i][j]) hipEventDestroy(c->mark_ev[i][j]);
   for (int i = 0; i < NBUF; i++) { if (c->d_cntb[i]) hipFree(c->d_cntb[i]); if (c->d_tmin[i]) hipFree(c->d_tmin[i]); if (c->d_rtb[i]) hipFree(c->d_rtb[i]); }
   for (int i = 0; i < NBUF; i++) { if (c->scan_done[i]) hipEventDestroy(c->scan_done[i]); if (c->replay_done[i]) hipEventDestroy(c->replay_done[i]); }
   for (int i_ = 0; i_ < 3; i_++) if (c->derive_streams[i_]) { hipStreamSynchronize(c->derive_streams[i_]); hipStreamDestroy(c->derive_streams[i_]); }
@@ -608,6 +617,7 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   if (c->scan_R == 4 && c->scan_NW != 8) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "four reference tiles per wave go with eight waves per block"); }
   if (tn.subslice_refs) { c->subslice = tn.subslice_refs; c->subslice_forced = true; }
   if (tn.rederive_streams >= 1 && tn.rederive_streams <= 3) c->derive_nstreams = tn.rederive_streams;
+  if (tn.replay_phases == 1 || tn.replay_phases == 2) c->replay_phases = tn.replay_phases;
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
   // four-counter scan instead (32-bit counts, same results, slower)
   if (c->nchar > 49000) c->fullscan = true;
@@ -940,6 +950,8 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #define BIGHEAP(A, B, PF_) OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<A, B, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
     BIGHEAP(true, true, 1); BIGHEAP(true, false, 1); BIGHEAP(false, true, 1); BIGHEAP(false, false, 1);
     BIGHEAP(true, true, 2); BIGHEAP(true, false, 2); BIGHEAP(false, true, 2); BIGHEAP(false, false, 2);
@@ -1573,6 +1585,39 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   const uint32_t *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
+  if (c->scan_variant == 0 && c->replay_phases != 1 && (c->replay_phases == 2 || c->nq <= 32)) {
+    // A handful of queries: candidates in parallel, then the ordered machine over their records (kernels_replay3.inc)
+    const size_t need = (size_t)n_tiles;
+    if (!c->d_summary || c->cand_tiles_cap < need) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (c->d_cand_mask) hipFree(c->d_cand_mask);
+      if (c->d_cand_rec) hipFree(c->d_cand_rec);
+      c->d_cand_mask = nullptr; c->d_cand_rec = nullptr; c->cand_tiles_cap = 0;
+      if (!c->d_summary) HIPCHK(c, hipMalloc(&c->d_summary, (size_t)c->nq * 8 * sizeof(int)));
+      const size_t cap = need + need / 8 + 64;
+      HIPCHK(c, hipMalloc(&c->d_cand_mask, (size_t)c->nq * cap * sizeof(unsigned long long)));
+      HIPCHK(c, hipMalloc(&c->d_cand_rec, (size_t)c->nq * cap * 64 * 2 * sizeof(int4)));
+      c->cand_tiles_cap = cap;
+    }
+    const int nqr = q1 - q0;
+    // tiles per candidate wave: enough waves to fill the chip, few enough that a wave's set-up (the query's ambiguity list) is shared
+    const int tpw = std::max(1, std::min(64, (int)(((size_t)n_tiles * nqr + 8191) / 8192)));
+    dim3 gridc((unsigned)((n_tiles + tpw - 1) / tpw), (unsigned)nqr);
+    // (rows of d_cand_mask / d_cand_rec are indexed by query number with the slice's own pitch: shift the bases as uvaia_gpu_shard_replay does)
+    unsigned long long *cm = c->d_cand_mask; int4 *cr = c->d_cand_rec;
+#define PHASES(A, B) { hipLaunchKernelGGL((heap_summary_kernel<A>), dim3(nqr), dim3(64), 0, c->stream, c->d_heap, c->d_n, c->k, q0, c->d_summary); \
+      hipLaunchKernelGGL((candidates_kernel<A, B>), gridc, dim3(64), 0, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, c->d_summary, c->d_snap, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, \
+                         q0, n_tiles, tpw, cm, cr, c->d_stats); \
+      hipLaunchKernelGGL((replay3_kernel<A>), dim3(nqr), dim3(64), lds + 128, c->stream, cm, cr, ppad, n_tiles, rb, (long long)ordinal0, c->d_heap, c->d_n, c->d_T, ent, c->k, c->d_stats, q0); }
+    if (c->acgt) { if (c->n_idx_c > 0) PHASES(true, true) else PHASES(true, false) }
+    else         { if (c->n_idx_c > 0) PHASES(false, true) else PHASES(false, false) }
+#undef PHASES
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->replay_done[buf], c->stream));
+    c->replay_recorded[buf] = true;
+    c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf; c->last_rt = c->d_rtb[buf];
+    return 0;
+  }
 #define REPLAY2P(A, B, PF_) hipLaunchKernelGGL((replay2_kernel<A, B, PF_>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
                                   (c->scan_variant == 2 && c->shard_world == 1) ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)
@@ -1683,6 +1728,41 @@ int uvaia_gpu_replay_wait(uvaia_gpu_ctx *c)
 {
   if (!c) return UVAIA_GPU_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- ordering against a stream the caller owns (the stream its collectives run on) by events, without involving the host: what lets
+// the reference-shard driver queue scan -> exchange -> replay of stripe after stripe asynchronously (uvaia_amd/refshard.py).
+// A mark = the scans (or replays) issued so far, remembered under a slot number; a caller stream can be made to wait for a mark, and
+// the engine's later scans (or replays) for what a caller stream holds now.
+int uvaia_gpu_mark(uvaia_gpu_ctx *c, int what, int slot)
+{
+  if (!c || slot < 0 || slot >= 8 || (what != UVAIA_GPU_SCANS && what != UVAIA_GPU_REPLAYS)) return c ? fail(c, UVAIA_GPU_EINVAL, "mark: what = scans or replays, slot 0..7") : UVAIA_GPU_EINVAL;
+  for (int i = 0; i < 3; i++) {
+    hipEvent_t &e = c->mark_ev[slot][i];
+    hipStream_t st = what == UVAIA_GPU_SCANS ? c->scan_streams[i] : (i == 0 ? c->stream : nullptr);
+    c->mark_set[slot][i] = false;
+    if (!st) continue;
+    if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(e, st));
+    c->mark_set[slot][i] = true;
+  }
+  return 0;
+}
+int uvaia_gpu_stream_wait_mark(uvaia_gpu_ctx *c, void *stream, int slot)
+{
+  if (!c || slot < 0 || slot >= 8) return c ? fail(c, UVAIA_GPU_EINVAL, "slot 0..7") : UVAIA_GPU_EINVAL;
+  for (int i = 0; i < 3; i++) if (c->mark_set[slot][i]) HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->mark_ev[slot][i], 0));
+  return 0;
+}
+int uvaia_gpu_wait_stream(uvaia_gpu_ctx *c, int what, void *stream)
+{
+  if (!c || (what != UVAIA_GPU_SCANS && what != UVAIA_GPU_REPLAYS)) return c ? fail(c, UVAIA_GPU_EINVAL, "wait_stream: what = scans or replays") : UVAIA_GPU_EINVAL;
+  hipEvent_t &e = c->order_ev[c->order_rr++ % 16];
+  if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(e, (hipStream_t)stream));
+  if (what == UVAIA_GPU_REPLAYS) HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+  else for (int i = 0; i < 3; i++) if (c->scan_streams[i]) HIPCHK(c, hipStreamWaitEvent(c->scan_streams[i], e, 0));
   return 0;
 }
 

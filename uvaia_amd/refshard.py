@@ -127,9 +127,11 @@ class TorchExchange:
                 offs[r] = at
                 at += out_split[r]
             where.append({r: recv.data_ptr() + 4 * offs[r] for r in by_owner})
-        if self.device != "cpu":
-            torch.cuda.current_stream().synchronize()           # the engine's streams are not torch's: order through the host
         return [(where[0][p.owner], where[1][p.owner]) for p in stripe]
+
+    def stream(self):
+        """the stream the collectives run on (RCCL: torch's current stream), as the engine's ordering calls take it"""
+        return self.torch.cuda.current_stream().cuda_stream
 
 
 def run(engine, plan, xchg, cons, ordinal0=0):
@@ -154,16 +156,38 @@ def run(engine, plan, xchg, cons, ordinal0=0):
                 if p.owner == plan.rank:
                     engine.shard_scan(p.first, p.n, xchg.send_cnt[buf].data_ptr(), xchg.send_tmin[buf].data_ptr())
 
+        # On device buffers (RCCL) nothing below blocks the host: the scan stream, the stream of the collectives and the replay stream
+        # are ordered by events (uvaia_gpu_mark / stream_wait_mark / wait_stream).  Marks 0, 1 = the scan into send[0], send[1];
+        # 2, 3 = the replays that read recv[0], recv[1].  Over gloo the buffers are pinned host memory and the collectives run on
+        # the host: there the host waits.
+        on_device = xchg.device != "cpu" and hasattr(engine, "mark")
+        SCANS, REPLAYS = 0, 1
         scan(0, stripe_no & 1)
+        if on_device:
+            engine.mark(SCANS, stripe_no & 1)
         for k, stripe in enumerate(stripes):
             buf = stripe_no & 1
-            engine.scan_wait()                                   # this stripe's counters are complete
+            if on_device:
+                engine.stream_wait_mark(xchg.stream(), buf)      # the exchange's input: this stripe's scan
+            else:
+                engine.scan_wait()                               # this stripe's counters are complete
             if k + 1 < len(stripes):
+                if on_device:
+                    engine.wait_stream(SCANS, xchg.stream())     # send[buf ^ 1] is still being read by the exchange of the stripe before
                 scan(k + 1, buf ^ 1)                             # the next scan runs while this stripe is exchanged and replayed
-            if stripe_no >= 2:
-                engine.replay_wait()                             # recv[buf] was read by the replays of two stripes ago
+                if on_device:
+                    engine.mark(SCANS, buf ^ 1)
+            if stripe_no >= 2:                                   # recv[buf] was read by the replays of two stripes ago
+                if on_device:
+                    engine.stream_wait_mark(xchg.stream(), 2 + buf)
+                else:
+                    engine.replay_wait()
             got = xchg.exchange(buf, stripe)
+            if on_device:
+                engine.wait_stream(REPLAYS, xchg.stream())       # the replays below read what the exchange delivers
             if active:
                 for p, (cnt_ptr, tmin_ptr) in zip(stripe, got):  # stream order
                     engine.shard_replay(cnt_ptr, tmin_ptr, p.first, p.n, ordinal0 + p.first, plan.q0, plan.q1)
+            if on_device:
+                engine.mark(REPLAYS, 2 + buf)
             stripe_no += 1

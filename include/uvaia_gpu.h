@@ -79,9 +79,7 @@ typedef struct {
   int scan_tiles_per_wave;     /* column-compressed scan: 1, 2 or 4 tiles of 64 references per wave (default 2; 4 only with 8 waves per block) */
   int scan_waves_per_block;    /* column-compressed scan: 4 or 8 waves share a super-tile of 64 queries (default 8) */
   int rederive_streams;        /* uvaia_gpu_db_rederive: its chunks alternate over 1..3 streams (default 3: all chunks in flight at once, the first still done first) */
-  int replay_phases;           /* ordered replay: 1 = one kernel per slice (replay2_kernel), 2 = candidates in parallel + the ordered machine over their records
-                                  wherever that applies (the packed-plane scan); 0 = two phases up to 32 queries */
-  int reserved[6];             /* zero */
+  int reserved[7];             /* zero */
 } uvaia_gpu_tuning;
 int uvaia_gpu_open_tuned (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning /* may be NULL */);
 void uvaia_gpu_close (uvaia_gpu_ctx *ctx);

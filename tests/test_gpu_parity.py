@@ -549,11 +549,10 @@ def _resident_search(q, refs, pool, nbest, tuning=None):
 
 
 @pytest.mark.parametrize("acgt", [False, True])
-@pytest.mark.parametrize("phases", [1, 2])
-def test_two_phase_replay_of_few_queries_many_states(acgt, phases):
-    """A handful of queries over a resident database: candidates in parallel + the ordered machine over their records
-    (kernels_replay3.inc, the default up to 32 queries) and the one-kernel replay must both reproduce the oracle on many tiny
-    problems with heavy ties, tiny heaps and tiny pools (snapshots taken often: the cut pre-scores of src/nearest.c:431-432)."""
+def test_resident_search_of_few_queries_many_states(acgt):
+    """A handful of queries over a resident database (the packed-plane scan, sub-slices that wrap the ring of counter buffers) must
+    reproduce the oracle on many tiny problems with heavy ties, tiny heaps and tiny pools (snapshots taken often: the cut pre-scores
+    of src/nearest.c:431-432)."""
     rng = np.random.default_rng(17)
     for it in range(10):
         L = int(rng.integers(40, 260))
@@ -564,14 +563,14 @@ def test_two_phase_replay_of_few_queries_many_states(acgt, phases):
             continue
         pool, nbest = int(rng.integers(1, 70)), int(rng.integers(1, 12))
         gold = O.search(q, refs, _names(len(refs)), pool=pool, nbest=nbest, ambig_r=1.0)
-        rows, T, ent = _resident_search(q, refs, pool, nbest, tuning={"replay_phases": phases, "subslice_refs": int(rng.integers(64, 200))})
+        rows, T, ent = _resident_search(q, refs, pool, nbest, tuning={"subslice_refs": int(rng.integers(64, 200))})
         assert rows == [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows], (it, pool, nbest)
         assert T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved), (it, pool, nbest)
 
 
-def test_two_phase_replay_reproduces_the_truncated_prescore():
-    """the quirk of test_truncated_consensus_prescore_is_reproduced through the resident path: the candidates' records are cut at the
-    batch snapshot exactly as cq->res would be, and a tolerance that rises above the snapshot inside the batch lets them in"""
+def test_resident_search_reproduces_the_truncated_prescore():
+    """the quirk of test_truncated_consensus_prescore_is_reproduced through the resident path: the pre-score is cut at the batch
+    snapshot exactly as cq->res would be, and a tolerance that rises above the snapshot inside the batch lets the cut scores in"""
     L = 400
     base = bytearray(b"A" * L)
     q = O.Query([bytes(base)], ["q0"])
@@ -585,20 +584,19 @@ def test_two_phase_replay_reproduces_the_truncated_prescore():
     refs = [ref_with(range(1, 11)), ref_with([20], n_sites=range(200, 400)), ref_with([]), ref_with([390, 395, 399])]
     for pool in (2, 4):
         gold = O.search(q, refs, _names(4), pool=pool, nbest=2, ambig_r=1.0)
-        for phases in (1, 2):
-            rows, T, _ = _resident_search(q, refs, pool, 2, tuning={"replay_phases": phases})
-            assert rows[0] == [(tuple(s), o) for o, _, s in gold.rows[0]], (pool, phases)
-            assert T == gold.final_T
+        rows, T, _ = _resident_search(q, refs, pool, 2)
+        assert rows[0] == [(tuple(s), o) for o, _, s in gold.rows[0]], pool
+        assert T == gold.final_T
     gold = O.search(q, refs, _names(4), pool=2, nbest=2, ambig_r=1.0)
     assert (394, 394, 394, 396, 0, 400) in [tuple(s) for _, _, s in gold.rows[0]]
 
 
 @pytest.mark.parametrize("acgt", [False, True])
 @pytest.mark.parametrize("nq", [3, 32, 70])
-def test_two_phase_replay_at_genome_length(acgt, nq):
+def test_resident_search_of_few_queries_at_genome_length(acgt, nq):
     """generator data at full length (N runs, ambiguity codes: the on-demand counters of the default mode), several sub-slices, pools
-    that matter when the query set has constant-and-complete columns (3 queries) and when it has none; 70 queries on the packed-plane
-    scan with the two phases forced"""
+    that matter when the query set has constant-and-complete columns (3 queries) and when it has none; 70 queries forced onto the
+    packed-plane scan"""
     from uvaia_amd import hostlib
     gen = hostlib.Synth(29903, seed=20241008, preset=0)
     qs, _ = gen.generate_bytes(1 << 40, nq)
@@ -606,6 +604,6 @@ def test_two_phase_replay_at_genome_length(acgt, nq):
     refs = refs + qs[:2]
     q = O.Query(qs, _names(nq, "q"), acgt=acgt)
     gold = O.search(q, refs, _names(len(refs)), pool=700, nbest=25, ambig_r=0.5)
-    rows, T, ent = _resident_search(q, refs, 700, 25, tuning={"replay_phases": 2, "scan": "packed", "subslice_refs": 500})
+    rows, T, ent = _resident_search(q, refs, 700, 25, tuning={"scan": "packed", "subslice_refs": 500})
     assert rows == [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows]
     assert T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)

@@ -46,4 +46,21 @@ print({k: v for k, v in b["ball"].items() if k != "workload"})
 print({k: v for k, v in b["align"].items() if k not in ("note", "workload")})
 P
 fi
+
+if [[ $PART == *e* ]]; then
+for nq in 1 4 16 32; do for ph in 1; do
+  timeout -k 10 300 python bench.py --queries $nq --refs 1000000 --pool 1000000 --steps 5 --warmup 1 --no-sweep --cpu-refs 0 --parity-refs 4096  > $O/q${nq}_p$ph.json 2> $O/q${nq}_p$ph.err || { tail -5 $O/q${nq}_p$ph.err; exit 1; }
+  echo -n "queries $nq phases $ph: "; show $O/q${nq}_p$ph.json
+done; done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/q4trace -o q4 --output-format csv -- python bench.py --queries 4 --refs 1000000 --pool 1000000 --no-sweep --cpu-refs 0 --no-parity --steps 3 --warmup 1 > $O/q4trace.log 2>&1 || { tail -5 $O/q4trace.log; exit 1; }
+python - <<'P'
+import csv
+rows = list(csv.DictReader(open("gpurun_out/exp/q4trace/q4_kernel_trace.csv")))
+ks = [(r["Kernel_Name"].split("(")[0][:44], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
+t0 = None
+for k, s, e in ks[-22:]:
+    if t0 is None: t0 = s
+    print("%-46s start %8.1f end %8.1f dur %7.1f us" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3), flush=True)
+P
+fi
 echo done

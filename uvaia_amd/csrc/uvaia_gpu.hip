@@ -125,12 +125,8 @@ struct uvaia_gpu_ctx {
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
   uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 
   unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
-  // two-phase replay of a handful of queries (kernels_replay3.inc): per query the state the slice starts from, per (query, tile) the mask of
-  // the references that can still enter, per such reference its complete score vector
-  int *d_summary = nullptr; unsigned long long *d_cand_mask = nullptr; int4 *d_cand_rec = nullptr; size_t cand_tiles_cap = 0;
   hipEvent_t order_ev[16] = {}; unsigned order_rr = 0;   // uvaia_gpu_wait_stream: ordering against a caller-owned stream
   hipEvent_t mark_ev[8][3] = {}; bool mark_set[8][3] = {}; // uvaia_gpu_mark
-  int replay_phases = 0;         // 0 = by query count (two phases up to 32 queries on the packed-plane scan), 1 = always one kernel, 2 = two phases wherever they apply
   bool fullscan = false;         // four-counter scan + the replay over it (alignments above 49 000 columns; tuning.scan = UVAIA_GPU_SCAN_WIDE)
   size_t cnt_cap = 0;            // int4 elements allocated in d_cnt (lazily)
   uint32_t *d_cp = nullptr;      // consensus restricted to idx_c, one row [W4][4][NQ]
@@ -209,7 +205,6 @@ void fill_code_table(uint8_t *t)
 #include "kernels_scan_history.inc"
 #include "kernels_scan3.inc"
 #include "kernels_replay.inc"
-#include "kernels_replay3.inc"
 #include "kernels_ball.inc"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -558,7 +553,7 @@ void uvaia_gpu_close(uvaia_gpu_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto &e : c->evts) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  void *dev[] = {c->d_summary, c->d_cand_mask, c->d_cand_rec, c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
+  void *dev[] = {c->d_idx_cols, c->d_qg, c->d_ball_key, c->d_split, c->d_qrare, c->d_rmask, c->d_batch_grp, c->d_db_grp, c->d_cls, c->d_qpl, c->d_stream, c->d_sdir, c->d_batch_ev, c->d_batch_poly, c->d_db_ev, c->d_db_poly, c->d_batch_tote, c->d_db_tote,
                  c->d_batch_tot, c->d_db_tot, c->d_mindist, c->d_ball_list, c->d_ball_cdist, c->d_ball_n, c->d_ball_tiles, c->d_qp2, c->d_amb_q, c->d_batch_amb, c->d_db_amb, c->d_cnt2, c->d_stats, c->d_qp, c->d_cp, c->d_cpm, c->d_qpoly, c->d_pmask, c->d_heap, c->d_n, c->d_T, c->d_snap, c->d_err, c->d_batch, c->d_batch_nonn,
                  c->d_cnt, c->d_rt, c->d_tr, c->d_entered, c->d_stage, c->d_db, c->d_db_nonn};
   for (void *p : dev) if (p) hipFree(p);
@@ -617,7 +612,6 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
   if (c->scan_R == 4 && c->scan_NW != 8) { delete c; return fail(nullptr, UVAIA_GPU_EINVAL, "four reference tiles per wave go with eight waves per block"); }
   if (tn.subslice_refs) { c->subslice = tn.subslice_refs; c->subslice_forced = true; }
   if (tn.rederive_streams >= 1 && tn.rederive_streams <= 3) c->derive_nstreams = tn.rederive_streams;
-  if (tn.replay_phases == 1 || tn.replay_phases == 2) c->replay_phases = tn.replay_phases;
   // the default scan keeps per-pair deficits in 16-bit halves (LDS counters): alignments of more than ~49 000 columns take the
   // four-counter scan instead (32-bit counts, same results, slower)
   if (c->nchar > 49000) c->fullscan = true;
@@ -950,8 +944,6 @@ int uvaia_gpu_open_tuned(uvaia_gpu_ctx **out, const uvaia_gpu_query *q, int heap
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #define BIGHEAP(A, B, PF_) OPENCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&replay2_kernel<A, B, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
     BIGHEAP(true, true, 1); BIGHEAP(true, false, 1); BIGHEAP(false, true, 1); BIGHEAP(false, false, 1);
     BIGHEAP(true, true, 2); BIGHEAP(true, false, 2); BIGHEAP(false, true, 2); BIGHEAP(false, false, 2);
@@ -1585,39 +1577,6 @@ int uvaia_gpu_slice_replay_range(uvaia_gpu_ctx *c, int buf, int64_t ordinal0, in
   const uint32_t *cnt = buf ? c->d_cntb[buf] : c->d_cnt2;
   const int *nonn = c->d_db_nonn + tf * 64, *amb = c->d_db_amb + tf * 64 * AMB_ROW;
   uint8_t *ent = c->d_entered + tf * 64;
-  if (c->scan_variant == 0 && c->replay_phases != 1 && (c->replay_phases == 2 || c->nq <= 32)) {
-    // A handful of queries: candidates in parallel, then the ordered machine over their records (kernels_replay3.inc)
-    const size_t need = (size_t)n_tiles;
-    if (!c->d_summary || c->cand_tiles_cap < need) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (c->d_cand_mask) hipFree(c->d_cand_mask);
-      if (c->d_cand_rec) hipFree(c->d_cand_rec);
-      c->d_cand_mask = nullptr; c->d_cand_rec = nullptr; c->cand_tiles_cap = 0;
-      if (!c->d_summary) HIPCHK(c, hipMalloc(&c->d_summary, (size_t)c->nq * 8 * sizeof(int)));
-      const size_t cap = need + need / 8 + 64;
-      HIPCHK(c, hipMalloc(&c->d_cand_mask, (size_t)c->nq * cap * sizeof(unsigned long long)));
-      HIPCHK(c, hipMalloc(&c->d_cand_rec, (size_t)c->nq * cap * 64 * 2 * sizeof(int4)));
-      c->cand_tiles_cap = cap;
-    }
-    const int nqr = q1 - q0;
-    // tiles per candidate wave: enough waves to fill the chip, few enough that a wave's set-up (the query's ambiguity list) is shared
-    const int tpw = std::max(1, std::min(64, (int)(((size_t)n_tiles * nqr + 8191) / 8192)));
-    dim3 gridc((unsigned)((n_tiles + tpw - 1) / tpw), (unsigned)nqr);
-    // (rows of d_cand_mask / d_cand_rec are indexed by query number with the slice's own pitch: shift the bases as uvaia_gpu_shard_replay does)
-    unsigned long long *cm = c->d_cand_mask; int4 *cr = c->d_cand_rec;
-#define PHASES(A, B) { hipLaunchKernelGGL((heap_summary_kernel<A>), dim3(nqr), dim3(64), 0, c->stream, c->d_heap, c->d_n, c->k, q0, c->d_summary); \
-      hipLaunchKernelGGL((candidates_kernel<A, B>), gridc, dim3(64), 0, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, c->d_summary, c->d_snap, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, \
-                         q0, n_tiles, tpw, cm, cr, c->d_stats); \
-      hipLaunchKernelGGL((replay3_kernel<A>), dim3(nqr), dim3(64), lds + 128, c->stream, cm, cr, ppad, n_tiles, rb, (long long)ordinal0, c->d_heap, c->d_n, c->d_T, ent, c->k, c->d_stats, q0); }
-    if (c->acgt) { if (c->n_idx_c > 0) PHASES(true, true) else PHASES(true, false) }
-    else         { if (c->n_idx_c > 0) PHASES(false, true) else PHASES(false, false) }
-#undef PHASES
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->replay_done[buf], c->stream));
-    c->replay_recorded[buf] = true;
-    c->last_tiles = c->d_db; c->last_nonn = nonn; c->last_n = re - rb; c->last_rbegin = rb; c->last_ppad = ppad; c->last_ntiles = n_tiles; c->last_tile_first = tf; c->last_rt = c->d_rtb[buf];
-    return 0;
-  }
 #define REPLAY2P(A, B, PF_) hipLaunchKernelGGL((replay2_kernel<A, B, PF_>), dim3(q1 - q0), dim3(64), lds + (size_t)lq_words * 4 + 128, c->stream, cnt, ppad, c->d_rtb[buf], c->d_cp, nonn, amb, rb, re, (long long)ordinal0, \
                                   c->d_heap, c->d_n, c->d_T, c->d_snap, ent, c->k, c->d_db, tf, c->W4, c->d_qp, c->d_amb_q, c->d_stats, q0, (c->scan_variant == 2 || c->scan_variant == 0) ? c->d_tmin[buf] : (const int2 *)nullptr, \
                                   (c->scan_variant == 2 && c->shard_world == 1) ? c->d_qpl : (const uint32_t *)nullptr, lq_words, c->replay_prio, c->d_db_poly, c->NP4 + c->NR4, c->NP4, c->NR4, c->d_qrare)

@@ -63,4 +63,18 @@ for k, s, e in ks[-22:]:
     print("%-46s start %8.1f end %8.1f dur %7.1f us" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3), flush=True)
 P
 fi
+
+if [[ $PART == *f* ]]; then
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/c1trace -o c1 --output-format csv -- python bench.py --no-sweep --cpu-refs 0 --no-parity --steps 4 --warmup 1 > $O/c1trace.log 2>&1 || { tail -5 $O/c1trace.log; exit 1; }
+python - <<'P'
+import csv
+rows = list(csv.DictReader(open("gpurun_out/exp/c1trace/c1_kernel_trace.csv")))
+ks = sorted([(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40]) for r in rows])
+# the last complete step = from the last init_state_kernel but one... print the last 20 kernels
+t0 = None
+for s, e, k in ks[-19:]:
+    if t0 is None: t0 = s
+    print("%-42s start %8.1f end %8.1f dur %7.1f us" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3), flush=True)
+P
+fi
 echo done

@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 QUERY_INDEX0 = 1 << 40           # queries come from the same generator, disjoint sequence numbers
-KERNEL_SOURCES = ["uvaia_gpu.hip", "kernels_pack.inc", "kernels_scan_history.inc", "kernels_scan3.inc", "kernels_consensus.inc", "kernels_replay.inc", "kernels_ball.inc"]
+KERNEL_SOURCES = ["uvaia_gpu.hip", "kernels_pack.inc", "kernels_scan_history.inc", "kernels_scan3.inc", "kernels_consensus.inc", "kernels_replay.inc", "kernels_ball.inc",
+                  "host_launch.inc", "host_open.inc", "host_batch.inc", "host_resident.inc", "host_shards.inc", "host_ball.inc"]
 
 
 def parse(argv=None):
@@ -167,11 +168,11 @@ def attach_pmc_traffic(roofline, n_query, refs, pool, mode):
     """HBM-side traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process): quoted only
     when those passes measured THIS build of the kernels (hash of the kernel sources) on this workload; otherwise `traffic` stays null."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
     except Exception:
         return
     if pm.get("kernel_source_hash") != kernel_source_hash():
-        roofline["traffic_note"] = "profiles/r02_pmc_traffic.json was measured on another build of the kernels: not quoted"
+        roofline["traffic_note"] = "profiles/r03_pmc_traffic.json was measured on another build of the kernels: not quoted"
         return
     e = pm.get(roofline["kernel"])
     if not e:
@@ -180,7 +181,7 @@ def attach_pmc_traffic(roofline, n_query, refs, pool, mode):
     if all(cfg.get(k) == v for k, v in (("queries", n_query), ("refs_per_gpu", refs), ("pool", pool), ("mode", mode))):
         roofline["traffic"] = e["hbm_side_read_bytes_per_launch"] + e["write_bytes_per_launch"]
         roofline["traffic_note"] = ("FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch, separate --pmc passes of this build "
-                                    "(profiles/r02_pmc_traffic.json, kernel source hash %s); L2 misses incl. Infinity-Cache hits" % pm["kernel_source_hash"])
+                                    "(profiles/r03_pmc_traffic.json, kernel source hash %s); L2 misses incl. Infinity-Cache hits" % pm["kernel_source_hash"])
         if e.get("issue"):
             roofline["issue"] = e["issue"]
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copies the results of tools/measure_round.sh (gpurun_out/measure/) into profiles/ under round-2 names and writes
-profiles/r02_pmc_traffic.json, the block bench.py quotes for `roofline.traffic` (only for the build of the kernels it was measured
+"""Copies the results of tools/measure_round.sh (gpurun_out/measure/) into profiles/ under round-3 names and writes
+profiles/r03_pmc_traffic.json, the block bench.py quotes for `roofline.traffic` (only for the build of the kernels it was measured
 on: it carries the hash of the kernel sources).  Usage: python tools/collect_profiles.py"""
 import json
 import os
@@ -19,16 +19,18 @@ def last_json(path):
 
 def main():
     import bench
-    for src, dst in (("bench_default.json", "r02_bench_default.json"), ("bench_acgt_c1.json", "r02_bench_c1_acgt.json"),
-                     ("stats/c1_kernel_stats.csv", "r02_bench_c1_kernel_stats.csv"),
-                     ("pmc_fetch/f_counter_collection.csv", "r02_pmc_fetch_counter_collection.csv"), ("pmc_write/w_counter_collection.csv", "r02_pmc_write_counter_collection.csv"),
-                     ("pmc_fetch_q4/f_counter_collection.csv", "r02_pmc_fetch_q4_counter_collection.csv"),
-                     ("pmc_sqa/a_counter_collection.csv", "r02_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r02_pmc_sq_b_counter_collection.csv"),
-                     ("q4/q4_kernel_stats.csv", "r02_q4_1Mrefs_kernel_stats.csv"), ("q4/q4_kernel_trace.csv", "r02_q4_1Mrefs_kernel_trace.csv"),
-                     ("hbm_read.txt", "r02_hbm_read_ceiling.txt"), ("push_rate.json", "r02_push_rate.json"), ("ingest.json", "r02_ingest_text_vs_packed.json"),
-                     ("emu_refshard_2.json", "r02_emulated_reference_shards_2.json"), ("emu_refshard_4.json", "r02_emulated_reference_shards_4.json"),
-                     ("emu_refshard_8.json", "r02_emulated_reference_shards_8.json"), ("align_cli.json", "r02_uvaialign_cli_10k.json"),
-                     ("prune_timing.txt", "r02_query_preparation_timing.txt")):
+    for src, dst in (("bench_default.json", "r03_bench_default.json"), ("bench_acgt_c1.json", "r03_bench_c1_acgt.json"),
+                     ("stats/c1_kernel_stats.csv", "r03_bench_c1_kernel_stats.csv"),
+                     ("pmc_fetch/f_counter_collection.csv", "r03_pmc_fetch_counter_collection.csv"), ("pmc_write/w_counter_collection.csv", "r03_pmc_write_counter_collection.csv"),
+                     ("pmc_fetch_q4/f_counter_collection.csv", "r03_pmc_fetch_q4_counter_collection.csv"),
+                     ("pmc_sqa/a_counter_collection.csv", "r03_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r03_pmc_sq_b_counter_collection.csv"),
+                     ("q4/q4_kernel_stats.csv", "r03_q4_1Mrefs_kernel_stats.csv"), ("q4/q4_kernel_trace.csv", "r03_q4_1Mrefs_kernel_trace.csv"),
+                     ("hbm_read.txt", "r03_hbm_read_ceiling.txt"), ("push_rate.json", "r03_push_rate.json"), ("ingest.json", "r03_ingest_text_vs_packed.json"),
+                     ("emu_refshard_2.json", "r03_emulated_reference_shards_2.json"), ("emu_refshard_4.json", "r03_emulated_reference_shards_4.json"),
+                     ("emu_refshard_8.json", "r03_emulated_reference_shards_8.json"), ("align_cli.json", "r03_uvaialign_cli_10k.json"),
+                     ("prune_timing.txt", "r03_query_preparation_timing.txt"),
+                     ("ball/ball_kernel_stats.csv", "r03_ball_kernel_stats.csv"), ("ball.json", "r03_ball.json"),
+                     ("c1trace/c1_kernel_trace.csv", "r03_config1_kernel_trace.csv")):
         if os.path.exists(os.path.join(M, src)):
             shutil.copyfile(os.path.join(M, src), os.path.join(P, dst))
     if not os.path.exists(os.path.join(M, "pmc_summary.json")):
@@ -73,7 +75,7 @@ def main():
         total_kb = q4f["FETCH_SIZE"]["sum"] / (q4f["FETCH_SIZE"]["n"] / 5.0)        # five launches per step (short head and tail slices)
         out["q4_1Mrefs_check"] = {"kernel": "scan2_iupac_kernel", "fetch_bytes_corrected_per_step": total_kb * 1024 * 2, "packed_bytes_per_step": 1000000 * 14976,
                                   "ratio": total_kb * 1024 * 2 / (1000000 * 14976.0)}
-    json.dump(out, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(P, "r03_pmc_traffic.json"), "w"), indent=1)
     print("profiles updated")
 
 

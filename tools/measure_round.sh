@@ -4,7 +4,7 @@
 #   b = --acgt config[1], the Q = 4 kernel timeline, push-path and ingest timings
 #   c = reference-shard emulation (2, 4, 8 contexts on one GPU)
 #   d = uvaialign: SQ counters of the aligner, the command line end to end; query preparation timings
-# (parts so that each fits one gpurun call; tools/collect_profiles.py turns the results into profiles/r02_*)
+# (parts so that each fits one gpurun call; tools/collect_profiles.py turns the results into profiles/r03_*)
 set -o pipefail
 PART=${1:-abcd}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -20,6 +20,8 @@ step pmc fetch;      timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE
 step pmc write;      timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- $C1 > $O/pmc_write.log 2>&1 || exit 1
 step pmc sq a;       timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM -d $O/pmc_sqa -o a --output-format csv -- $C1 > $O/pmc_sqa.log 2>&1 || exit 1
 step pmc sq b;       timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $O/pmc_sqb -o b --output-format csv -- $C1 > $O/pmc_sqb.log 2>&1 || exit 1
+step ball profile;   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/ball -o ball --output-format csv -- python bench.py --ball-only --steps 3 > $O/ball.json 2> $O/ball.err || exit 1
+step c1 timeline;    timeout -k 10 300 rocprofv3 --kernel-trace -d $O/c1trace -o c1 --output-format csv -- python bench.py --no-sweep --cpu-refs 0 --no-parity --steps 3 --warmup 1 > $O/c1trace.log 2>&1 || exit 1
 step pmc fetch q4;   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_q4 -o f --output-format csv -- python bench.py --queries 4 --refs 1000000 --pool 1000000 --steps 2 --warmup 1 --no-sweep --cpu-refs 0 --no-parity > $O/pmc_fetch_q4.log 2>&1 || exit 1
 python tools/pmc_summary.py config1_fetch=$(ls $O/pmc_fetch/*counter_collection.csv) config1_write=$(ls $O/pmc_write/*counter_collection.csv) q4_1Mrefs_fetch=$(ls $O/pmc_fetch_q4/*counter_collection.csv) config1_sq_a=$(ls $O/pmc_sqa/*counter_collection.csv) config1_sq_b=$(ls $O/pmc_sqb/*counter_collection.csv) > $O/pmc_summary.json || exit 1
 fi

@@ -77,7 +77,7 @@ struct uvaia_gpu_ctx {
   struct DeriveChunk { long long t0, t1; hipEvent_t done; };
   hipStream_t derive_stream = nullptr;
   hipStream_t derive_streams[3] = {};     // [0] = derive_stream; the chunks of a rebuild alternate over the first derive_nstreams
-  int derive_nstreams = 3;
+  int derive_nstreams = 3; bool derive_forced = false;   // (forced: tuning.rederive_streams was given)
   std::vector<DeriveChunk> derive_chunks;
   hipEvent_t derive_fence[4] = {};
   size_t derive_pending = 0;          // chunks of the last rederive a scan may still have to wait for
@@ -135,7 +135,6 @@ struct uvaia_gpu_ctx {
   uint32_t *d_pmask = nullptr;   // [W4*4] mask of the polymorphic query columns (query->idx)
   int *d_mindist = nullptr, *d_ball_list = nullptr, *d_ball_cdist = nullptr, *d_ball_n = nullptr; size_t ball_cap = 0;   // radius search: results, the references that go on to the queries
   uint4 *d_ball_tiles = nullptr; size_t ball_tiles_cap = 0; unsigned long long ball_asked = 0;
-  int ball_split[10] = {};                                  // ball_gather_cols_kernel: word groups and gathered columns before each of its four waves
   int *d_idx_cols = nullptr; int n_idx = 0, NG4 = 0;       // query->idx (the polymorphic query columns) and the word groups they fill once gathered
   uint32_t *d_qg = nullptr;                                 // the queries on those columns (kernels_ball.inc), built by the first radius search
   unsigned long long *d_ball_key = nullptr;                 // per listed reference: first query that ends the reference's loop (query << 32 | distance)

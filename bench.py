@@ -458,8 +458,9 @@ def parity_on_refshard(O, capi, refshard, dist, pq, gen, qseqs, qnames, mode, nb
         e2.db_set_shard(rank, world, plan.piece)
         e2.db_reserve(n_s)
         rows, non_n = gen.generate(0, n_s)
-        e2.db_append_block(rows, non_n)
+        e2.db_append_block(rows, non_n)                  # handed the whole stream: keeps the references of its own pieces
         x2 = refshard.TorchExchange(dist, plan, e2, "cuda" if on_gpu else "cpu", pinned=not on_gpu)
+        x2.connect_peers(e2)
         e2.reset()
         e2.db_rederive()
         refshard.run(e2, plan, x2, len(pq.idx_c) > 0)
@@ -468,6 +469,7 @@ def parity_on_refshard(O, capi, refshard, dist, pq, gen, qseqs, qnames, mode, nb
         got = capi.finalise_heaps(n, sc, od)
         for iq in range(plan.q0, plan.q1):
             ok = ok and got[iq] == [(tuple(s_), o) for o, _, s_ in gold.rows[iq]] and int(T[iq]) == gold.final_T[iq]
+        x2.disconnect_peers(e2)
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(int(t.item()) == 1)
@@ -569,8 +571,8 @@ def main():
     emu = args.emulate_shard_of if (world == 1 and args.emulate_shard_of > 1) else 0
     multi = args.multi if world > 1 else ("shards" if emu else None)
     shard_mode = multi == "shards"
-    # query shards: every rank holds (and scans) the whole stream; reference shards: every rank holds the packed planes of the whole stream
-    # (the replay reads them) but derives and scans only its own pieces
+    # query shards: every rank holds (and scans) the whole stream; reference shards: the stream has world x refs references, a rank keeps,
+    # derives and scans only its own pieces (the capacity below is the stream's length: a context sizes its arrays for its share)
     local_refs = (emu or world) * args.refs if (shard_mode or multi == "refshard") else args.refs
     pool = min(args.pool, local_refs)
     from uvaia_amd import ring, shards
@@ -592,12 +594,20 @@ def main():
     # ring: block-cyclic shard, stripe s (= one pool of world*pool references of the stream) = slice s of rank 0, 1, ...
     # shards: the whole stream on every rank;  refshard: slice s of the stream = rank-major pieces, see uvaia_amd/refshard.py
     if multi == "refshard":
-        slices = plan.local_slices()
+        slices = []
+        for pc in plan.stream_pieces():              # its own pieces are generated and packed, the others only counted
+            if pc.owner == rank:
+                for a in range(0, pc.n, 8192):
+                    n = min(8192, pc.n - a)
+                    rows, non_n = gen.generate(pc.first + a, n)
+                    eng.db_append_block(rows, non_n)
+            else:
+                eng.db_skip(pc.n)
     elif shard_mode or world == 1:
         slices = [ring.Slice(0, local_refs, 0)]
     else:
         slices = ring.block_cyclic_layout(args.refs, pool, rank, world)
-    first = slices[0].ordinal0
+    first = slices[0].ordinal0 if slices else 0
     chunk = 8192
     for sl in slices:
         for a in range(0, sl.n, chunk):
@@ -612,6 +622,8 @@ def main():
     q0, q1 = shards.query_shard(pq.ntax, rank, emu or world) if shard_mode else (0, pq.ntax)
     allmax = shards.TorchMax(dist, "cuda" if on_gpu else "cpu") if (shard_mode and cons and dist is not None) else None
     xchg = refshard.TorchExchange(dist, plan, eng, "cuda" if on_gpu else "cpu", pinned=not on_gpu) if multi == "refshard" else None
+    if xchg is not None:
+        xchg.connect_peers(eng)
 
     # ---- timed region
     # One step = everything one search of the resident database costs for this query set: the planes derived from the packed
@@ -695,6 +707,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         parity = parity_on_refshard(O, capi, refshard, dist, pq, gen, qseqs, qnames, args.mode, args.nbest, world, rank, local_rank, on_gpu)
+    if xchg is not None:
+        xchg.disconnect_peers(eng)
     eng.close()
 
     # ---- other resident-query counts, driver-timed in the same run (rank 0, N=1 only)

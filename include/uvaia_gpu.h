@@ -198,15 +198,21 @@ int uvaia_gpu_set_active_queries (uvaia_gpu_ctx *ctx, int q0, int q1);
 int uvaia_gpu_max_tolerance (uvaia_gpu_ctx *ctx, int *out);
 int uvaia_gpu_search_resident_pool (uvaia_gpu_ctx *ctx, size_t first, size_t n, int64_t ordinal0, int snapshot);
 
-/* ---- reference shards: several GPUs, each deriving and scanning 1/N of the references against ALL queries and replaying 1/N of
+/* ---- reference shards: several GPUs, each keeping, deriving and scanning 1/N of the references against ALL queries and replaying 1/N of
  * the queries over ALL references (the default layout for several GPUs; DESIGN.md "Multi-GPU").  The scores of a pair do not
  * depend on anything but the pair, so the scan -- more than nine tenths of a search -- shards by reference; the gate + heap machine
  * of a query is sequential in stream order (src/nearest.c:488,504-508) but independent of the other queries, so the replay shards
  * by query; in between, the pair counters of a slice move once: rank r sends to rank d the rows of d's queries (one all-to-all per
  * slice over RCCL between processes -- uvaia_amd/refshard.py -- or peer copies inside one process -- uvaia_gpu_group_*).
  *   - the stream is dealt in pieces of piece_refs references (a whole number of tiles of 64); piece p belongs to rank p % world
- *   - every rank holds the PACKED planes of all references (query-independent; the replay reads a few words of the references
- *     that reach a heap), but the planes derived for the query set -- and all scanning -- only for its own pieces
+ *   - a rank KEEPS only its own pieces: packed planes, side rows, counts and the planes derived for the query set.  Appends are handed
+ *     the whole stream in order (uvaia_gpu_db_append* keep the context's share and count the rest; uvaia_gpu_db_skip moves the
+ *     stream position over references of other ranks without handing them over): every rank stages and packs 1/N of the database.
+ *   - a replaying rank needs, of a piece scanned elsewhere: the rows of its queries (cnt, tmin), a small block per reference (`aux`:
+ *     valid sites and, with constant-and-complete query columns, the untruncated consensus pre-score), and -- for the few pairs that
+ *     reach the exact comparison -- words of the reference's packed planes and its side row, which it READS IN PLACE from the rank
+ *     that keeps them: uvaia_gpu_shard_set_peer (one process: the other member's device pointers, peer access enabled) or
+ *     uvaia_gpu_shard_ipc_handles / _open (one process per GPU: hipIpc mappings, over xGMI on a node)
  *   - the one coupling between queries, the batch snapshot cq->max_incompatible = max over ALL heaps (src/nearest.c:290-291), is
  *     exchanged per batch when it can matter (query sets with constant-and-complete columns): uvaia_gpu_max_tolerance on the
  *     active queries of every rank, maximum over the ranks, uvaia_gpu_set_snapshot.
@@ -215,12 +221,22 @@ int uvaia_gpu_search_resident_pool (uvaia_gpu_ctx *ctx, size_t first, size_t n, 
  *                                                    valid pairs, with --acgt mismatches and comparable sites), row = query, a reference
  *                                                    in column (position - 64 * (first / 64)); tiles = tiles the range touches
  *   tmin int2 [uvaia_gpu_shard_rows()][tiles]        the two bounds per (query, tile) the replay skips tiles by
- *   both caller-owned device buffers; asynchronous on the scan stream, uvaia_gpu_scan_wait() returns when they are complete.
- * shard_replay: gate + heaps of queries [q0, q1) over references [first, first+n) (any rank's piece) from buffers of the same
- *   layout that hold ONLY the rows q0 .. q1-1; pieces must be replayed in stream order; asynchronous (uvaia_gpu_sync). */
+ *   aux  uvaia_gpu_shard_aux_bytes(tiles) bytes      int valid_sites[tiles * 64], then (constant-and-complete columns) int4 prescore[tiles * 64]
+ *   all caller-owned device buffers; asynchronous on the scan stream, uvaia_gpu_scan_wait() returns when they are complete.
+ * shard_replay: gate + heaps of queries [q0, q1) over references [first, first+n) -- a piece of rank `owner` -- from buffers of the same
+ *   layout that hold ONLY the rows q0 .. q1-1 and the piece's aux block; pieces must be replayed in stream order; asynchronous (uvaia_gpu_sync). */
 int uvaia_gpu_db_set_shard (uvaia_gpu_ctx *ctx, int rank, int world, size_t piece_refs);
 int uvaia_gpu_shard_rows (const uvaia_gpu_ctx *ctx);
-int uvaia_gpu_shard_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, void *cnt, void *tmin);
+size_t uvaia_gpu_shard_aux_bytes (const uvaia_gpu_ctx *ctx, size_t n_tiles);
+int uvaia_gpu_shard_scan (uvaia_gpu_ctx *ctx, size_t first, size_t n, void *cnt, void *tmin, void *aux);
+int uvaia_gpu_db_skip (uvaia_gpu_ctx *ctx, size_t n_ref);
+int uvaia_gpu_shard_set_peer (uvaia_gpu_ctx *ctx, int rank, const void *planes, const void *side_rows);
+const void *uvaia_gpu_shard_planes (const uvaia_gpu_ctx *ctx);
+const void *uvaia_gpu_shard_side_rows (const uvaia_gpu_ctx *ctx);
+int uvaia_gpu_shard_ipc_handle_bytes (void);
+int uvaia_gpu_shard_ipc_handles (uvaia_gpu_ctx *ctx, void *out /* uvaia_gpu_shard_ipc_handle_bytes() bytes */);
+int uvaia_gpu_shard_ipc_open (uvaia_gpu_ctx *ctx, int rank, const void *handles);
+int uvaia_gpu_shard_ipc_close (uvaia_gpu_ctx *ctx);     /* unmaps them again: every rank closes, then a barrier, then the owners may free */
 int uvaia_gpu_scan_wait (uvaia_gpu_ctx *ctx);
 int uvaia_gpu_replay_wait (uvaia_gpu_ctx *ctx);      /* replays issued so far are complete: their counter buffers may be overwritten */
 int uvaia_gpu_set_snapshot (uvaia_gpu_ctx *ctx, int snapshot);
@@ -235,7 +251,7 @@ enum { UVAIA_GPU_SCANS = 0, UVAIA_GPU_REPLAYS = 1 };
 int uvaia_gpu_mark (uvaia_gpu_ctx *ctx, int what, int slot);
 int uvaia_gpu_stream_wait_mark (uvaia_gpu_ctx *ctx, void *stream, int slot);
 int uvaia_gpu_wait_stream (uvaia_gpu_ctx *ctx, int what, void *stream);
-int uvaia_gpu_shard_replay (uvaia_gpu_ctx *ctx, const void *cnt, const void *tmin, size_t first, size_t n, int64_t ordinal0, int q0, int q1);
+int uvaia_gpu_shard_replay (uvaia_gpu_ctx *ctx, const void *cnt, const void *tmin, const void *aux, int owner, size_t first, size_t n, int64_t ordinal0, int q0, int q1);
 
 /* ---- a group of contexts driven by ONE host thread (the command line's --devices): the reference-shard protocol with peer copies
  * as the exchange; replaces the batch loop of src/nearest.c:245-330 for several GPUs.  devices[i] = HIP device of member i (a

@@ -59,7 +59,10 @@ class RefShardOracleEngine:
     def _view(ptr, n_ints):
         return np.ctypeslib.as_array((C.c_int32 * n_ints).from_address(ptr))
 
-    def shard_scan(self, first, n, cnt_ptr, tmin_ptr):
+    def shard_aux_bytes(self, n_tiles):
+        return n_tiles * 64 * 4                                  # one int per reference (the GPU engine: valid sites, + 16 bytes of pre-score)
+
+    def shard_scan(self, first, n, cnt_ptr, tmin_ptr, aux_ptr):
         assert (first // self.piece) % self.world == self.rank, "scans only its own pieces"
         assert first // self.piece == (first + n - 1) // self.piece
         t0 = first // 64
@@ -71,6 +74,7 @@ class RefShardOracleEngine:
             cnt[q, :] = (q * 1000003 + pos * 7 + 11) & 0x7FFFFFFF
             tmin[q, :, 0] = q
             tmin[q, :, 1] = t0 + np.arange(tiles)
+        self._view(aux_ptr, tiles * 64)[:] = (pos * 13 + 5 + 1000003 * self.rank) & 0x7FFFFFFF   # names (reference, scanning rank)
         self.scanned.append((first, n))
 
     def scan_wait(self):
@@ -88,10 +92,13 @@ class RefShardOracleEngine:
     def set_snapshot(self, v):
         self.snap = v
 
-    def shard_replay(self, cnt_ptr, tmin_ptr, first, n, ordinal0, q0, q1):
+    def shard_replay(self, cnt_ptr, tmin_ptr, aux_ptr, owner, first, n, ordinal0, q0, q1):
         t0 = first // 64
         tiles = (first + n + 63) // 64 - t0
         nq = q1 - q0
+        assert owner == (first // self.piece) % self.world, "the piece's scanning rank"
+        pos_ = t0 * 64 + np.arange(tiles * 64, dtype=np.int64)
+        assert np.array_equal(self._view(aux_ptr, tiles * 64), ((pos_ * 13 + 5 + 1000003 * owner) & 0x7FFFFFFF).astype(np.int32)), "aux block of another piece or rank"
         cnt = self._view(cnt_ptr, nq * tiles * 64).reshape(nq, tiles * 64)
         tmin = self._view(tmin_ptr, nq * tiles * 2).reshape(nq, tiles, 2)
         pos = t0 * 64 + np.arange(tiles * 64, dtype=np.int64)

@@ -23,6 +23,8 @@ SYMBOLS = [
     "uvaia_gpu_set_active_queries", "uvaia_gpu_max_tolerance", "uvaia_gpu_search_resident_pool",
     "uvaia_gpu_db_set_shard", "uvaia_gpu_shard_rows", "uvaia_gpu_shard_scan", "uvaia_gpu_scan_wait", "uvaia_gpu_replay_wait", "uvaia_gpu_set_snapshot", "uvaia_gpu_shard_replay",
     "uvaia_gpu_mark", "uvaia_gpu_stream_wait_mark", "uvaia_gpu_wait_stream",
+    "uvaia_gpu_shard_aux_bytes", "uvaia_gpu_db_skip", "uvaia_gpu_shard_set_peer", "uvaia_gpu_shard_planes", "uvaia_gpu_shard_side_rows",
+    "uvaia_gpu_shard_ipc_handle_bytes", "uvaia_gpu_shard_ipc_handles", "uvaia_gpu_shard_ipc_open", "uvaia_gpu_shard_ipc_close",
     "uvaia_gpu_group_open", "uvaia_gpu_group_close", "uvaia_gpu_group_last_error", "uvaia_gpu_group_size", "uvaia_gpu_group_member", "uvaia_gpu_group_query_shard",
     "uvaia_gpu_group_db_reserve", "uvaia_gpu_group_db_append", "uvaia_gpu_group_db_append_packed", "uvaia_gpu_group_db_clear", "uvaia_gpu_group_db_rederive",
     "uvaia_gpu_group_db_size", "uvaia_gpu_group_reset", "uvaia_gpu_group_search_resident", "uvaia_gpu_group_push", "uvaia_gpu_group_drain", "uvaia_gpu_group_sync",
@@ -142,11 +144,16 @@ def load_library():
         "uvaia_gpu_db_append_packed": (C.c_int, [vp, C.c_void_p, pi, pi, C.c_int]),
         "uvaia_gpu_db_set_shard": (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t]),
         "uvaia_gpu_shard_rows": (C.c_int, [vp]),
-        "uvaia_gpu_shard_scan": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+        "uvaia_gpu_shard_scan": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "uvaia_gpu_shard_aux_bytes": (C.c_size_t, [vp, C.c_size_t]), "uvaia_gpu_db_skip": (C.c_int, [vp, C.c_size_t]),
+        "uvaia_gpu_shard_set_peer": (C.c_int, [vp, C.c_int, C.c_void_p, C.c_void_p]),
+        "uvaia_gpu_shard_planes": (C.c_void_p, [vp]), "uvaia_gpu_shard_side_rows": (C.c_void_p, [vp]),
+        "uvaia_gpu_shard_ipc_handle_bytes": (C.c_int, []), "uvaia_gpu_shard_ipc_handles": (C.c_int, [vp, C.c_void_p]),
+        "uvaia_gpu_shard_ipc_open": (C.c_int, [vp, C.c_int, C.c_void_p]), "uvaia_gpu_shard_ipc_close": (C.c_int, [vp]),
         "uvaia_gpu_scan_wait": (C.c_int, [vp]),
         "uvaia_gpu_replay_wait": (C.c_int, [vp]),
         "uvaia_gpu_set_snapshot": (C.c_int, [vp, C.c_int]),
-        "uvaia_gpu_shard_replay": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64, C.c_int, C.c_int]),
+        "uvaia_gpu_shard_replay": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int64, C.c_int, C.c_int]),
         "uvaia_gpu_mark": (C.c_int, [vp, C.c_int, C.c_int]), "uvaia_gpu_stream_wait_mark": (C.c_int, [vp, C.c_void_p, C.c_int]),
         "uvaia_gpu_wait_stream": (C.c_int, [vp, C.c_int, C.c_void_p]),
         "uvaia_gpu_group_open": (C.c_int, [C.POINTER(vp), C.POINTER(_Query), C.c_int, pi, C.c_int, C.c_size_t, C.c_size_t]),
@@ -307,8 +314,27 @@ class Engine:
     def shard_rows(self):
         return self.L.uvaia_gpu_shard_rows(self.ctx)
 
-    def shard_scan(self, first, n, cnt_ptr, tmin_ptr):
-        self._chk(self.L.uvaia_gpu_shard_scan(self.ctx, int(first), int(n), C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr)))
+    def shard_scan(self, first, n, cnt_ptr, tmin_ptr, aux_ptr):
+        self._chk(self.L.uvaia_gpu_shard_scan(self.ctx, int(first), int(n), C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr), C.c_void_p(aux_ptr)))
+
+    def shard_aux_bytes(self, n_tiles):
+        return int(self.L.uvaia_gpu_shard_aux_bytes(self.ctx, int(n_tiles)))
+
+    def db_skip(self, n_ref):
+        """the next n_ref references of the stream belong to other ranks' pieces"""
+        self._chk(self.L.uvaia_gpu_db_skip(self.ctx, int(n_ref)))
+
+    def shard_ipc_handles(self):
+        """bytes that let another process map this context's packed planes and side rows (uvaia_gpu_shard_ipc_open there)"""
+        buf = C.create_string_buffer(self.L.uvaia_gpu_shard_ipc_handle_bytes())
+        self._chk(self.L.uvaia_gpu_shard_ipc_handles(self.ctx, buf))
+        return buf.raw
+
+    def shard_ipc_close(self):
+        self._chk(self.L.uvaia_gpu_shard_ipc_close(self.ctx))
+
+    def shard_ipc_open(self, rank, handles):
+        self._chk(self.L.uvaia_gpu_shard_ipc_open(self.ctx, int(rank), C.c_char_p(bytes(handles))))
 
     def scan_wait(self):
         self._chk(self.L.uvaia_gpu_scan_wait(self.ctx))
@@ -330,8 +356,8 @@ class Engine:
     def wait_stream(self, what, stream):
         self._chk(self.L.uvaia_gpu_wait_stream(self.ctx, int(what), C.c_void_p(stream)))
 
-    def shard_replay(self, cnt_ptr, tmin_ptr, first, n, ordinal0, q0, q1):
-        self._chk(self.L.uvaia_gpu_shard_replay(self.ctx, C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr), int(first), int(n), int(ordinal0), int(q0), int(q1)))
+    def shard_replay(self, cnt_ptr, tmin_ptr, aux_ptr, owner, first, n, ordinal0, q0, q1):
+        self._chk(self.L.uvaia_gpu_shard_replay(self.ctx, C.c_void_p(cnt_ptr), C.c_void_p(tmin_ptr), C.c_void_p(aux_ptr), int(owner), int(first), int(n), int(ordinal0), int(q0), int(q1)))
 
     def db_rederive(self):
         """Rebuild the query-set-dependent planes of the whole resident database (asynchronous)."""

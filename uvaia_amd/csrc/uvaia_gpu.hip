@@ -109,6 +109,8 @@ struct uvaia_gpu_ctx {
   // reference shards (uvaia_gpu_db_set_shard): the stream is dealt in pieces of shard_pt tiles, piece p belongs to rank p % world; the packed
   // planes of ALL references are resident (the replay reads them), the planes derived for the query set only for the owned pieces
   int shard_rank = 0, shard_world = 1; long long shard_pt = 0;
+  const uint4 *peer_db[64] = {}; const int *peer_amb[64] = {};      // packed planes and side rows of every rank's pieces, as this process can address them
+  void *ipc_opened[64][2] = {};                                    // mappings opened by uvaia_gpu_shard_ipc_open (closed with the context)
   uint32_t *d_qrare = nullptr;   // [nq][NR4*4][lo, hi, isACGT] the queries on the rare columns (--acgt: dist_unique of admitted pairs)
   int need_e_groups = 0, need_v_groups = 0, need_g_groups = 0, need_r_groups = 0;   // word groups whose E / V plane some query tile has to read (for the byte accounting)
   int act_q0 = 0, act_q1 = 0;    // active query range of the resident/slice paths (query shards across GPUs); whole set by default
@@ -154,7 +156,7 @@ struct uvaia_gpu_ctx {
   // resident database
   uint4 *d_db = nullptr;
   int *d_db_nonn = nullptr;
-  size_t db_cap = 0, db_n = 0;
+  size_t db_cap = 0, db_n = 0, db_local_tiles = 0;   // (db_n counts the stream; a context of a reference shard keeps db_local_tiles tiles of it)
   // last batch (introspection)
   const uint4 *last_tiles = nullptr; const int *last_nonn = nullptr; int last_n = 0, last_rbegin = 0, last_ppad = 0, last_ntiles = 0;
   long long last_tile_first = 0;
@@ -181,10 +183,24 @@ int fail(uvaia_gpu_ctx *c, int code, const char *fmt, ...)
 // inside an entry point that has a context: message into the context, return the code
 #define HIPCHK(c, call) HIP_TRY(call, return fail((c), code_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__))
 
-// reference shards: does this context keep derived planes for packed tile t, and under which number
+// Reference shards: the per-reference arrays of the resident database -- packed planes, side rows, counts, derived planes -- hold the
+// context's OWN pieces only, numbered densely ("local" tiles: dtile_of); positions in the stream, ordinals and the dump flags stay
+// global.  owns_tile: does this context keep (global) tile t;  dtile_of: its local number on the context that keeps it (the same formula
+// on every rank: a replaying rank uses it to find a reference in the memory of the rank that scanned it).
 inline bool owns_tile(const uvaia_gpu_ctx *c, long long t) { return c->shard_world == 1 || (t / c->shard_pt) % c->shard_world == c->shard_rank; }
 inline long long dtile_of(const uvaia_gpu_ctx *c, long long t)
 { return c->shard_world == 1 ? t : (t / (c->shard_pt * c->shard_world)) * c->shard_pt + t % c->shard_pt; }
+// the owned parts of the global tiles [gt0, gt1): f(global first tile, local first tile, number of tiles) per part inside one piece
+template <class F> inline int for_owned_tiles(const uvaia_gpu_ctx *c, long long gt0, long long gt1, F f)
+{
+  if (c->shard_world == 1) return gt1 > gt0 ? f(gt0, gt0, gt1 - gt0) : 0;
+  for (long long a = gt0; a < gt1;) {
+    const long long b = std::min(gt1, (a / c->shard_pt + 1) * c->shard_pt);
+    if (owns_tile(c, a)) { const int rc = f(a, dtile_of(c, a), b - a); if (rc) return rc; }
+    a = b;
+  }
+  return 0;
+}
 inline size_t derived_tiles(const uvaia_gpu_ctx *c, size_t tiles)
 { return c->shard_world == 1 ? tiles : (size_t)((tiles + (size_t)(c->shard_pt * c->shard_world) - 1) / (size_t)(c->shard_pt * c->shard_world)) * (size_t)c->shard_pt; }
 

@@ -13,9 +13,11 @@ What shards how (include/uvaia_gpu.h "reference shards", DESIGN.md "Multi-GPU"):
   * the one coupling between queries, the batch snapshot (src/nearest.c:290-291), is a maximum over all ranks per batch, and only
     when the query set has constant-and-complete columns.
 
-Layout: the stream is dealt in pieces of `piece` references (whole tiles of 64); piece p belongs to rank p % world.  Every rank
-holds the packed planes of the whole stream (query-independent; the replay reads a few words of the references that reach a heap),
-the planes derived for the query set only for its own pieces: per-GPU memory is 15 KB x all references + 10 KB x its own.
+Layout: the stream is dealt in pieces of `piece` references (whole tiles of 64); piece p belongs to rank p % world.  A rank keeps
+only its own pieces -- packed planes, side rows, the planes derived for the query set: 25 KB x its own references -- and ingests
+only those.  What a replay needs of a piece scanned elsewhere travels with the counters (valid sites, consensus pre-score: the `aux`
+block, all-gathered per stripe); the few words of packed planes and side rows it reads for the pairs that reach the exact comparison
+are read in place from the rank that keeps them, through inter-process mappings set up once (TorchExchange.connect_peers).
 
 Any object with the engine's shard calls works as `engine` (uvaia_amd.capi.Engine on a GPU; the CPU tests drive the same protocol over
 gloo with an oracle-backed stand-in).
@@ -68,15 +70,15 @@ class Plan:
         pool = self.pool if cons else self.total
         return [(a, min(self.total, a + pool)) for a in range(0, self.total, pool)]
 
-    def local_slices(self):
-        """what bench.py loads on every rank: the whole stream (packed planes of all references are resident everywhere)"""
-        from .ring import Slice
-        return [Slice(0, self.total, 0)]
+    def stream_pieces(self):
+        """the whole stream as pieces of the shard map, in order: what a rank walks while loading (its own pieces are appended, the
+        others skipped: uvaia_gpu_db_skip)"""
+        return self.pieces_of_pool(0, self.total)
 
     def describe(self):
         return ("reference shards: every GPU derives and scans its pieces of %d references (1/%d of the %d-reference stream) against all %d queries, "
                 "one RCCL all-to-all per stripe moves the pair counters to the GPU that replays the query (%d queries per GPU, stream order); "
-                "packed planes replicated, derived planes sharded; exact" % (self.piece, self.world, self.total, self.n_query, self.q1 - self.q0))
+                "every GPU keeps and ingests its own pieces only (packed and derived planes; remote words read in place over hipIpc mappings); exact" % (self.piece, self.world, self.total, self.n_query, self.q1 - self.q0))
 
 
 class TorchExchange:
@@ -97,9 +99,32 @@ class TorchExchange:
         self.send_tmin = [mk(rows * (cols // 64) * 2) for _ in range(2)]
         self.recv_cnt = [mk(plan.world * my * cols) for _ in range(2)]
         self.recv_tmin = [mk(plan.world * my * (cols // 64) * 2) for _ in range(2)]
+        self.aux_ints = (engine.shard_aux_bytes(cols // 64) + 3) // 4         # per piece: valid sites (+ consensus pre-score) of its references
+        self.send_aux = [mk(self.aux_ints) for _ in range(2)]
+        self.recv_aux = [mk(plan.world * self.aux_ints) for _ in range(2)]
         self.maxbuf = torch.zeros(1, dtype=torch.int32, device=device)
         if device != "cpu":
             torch.cuda.current_stream().synchronize()
+
+    def connect_peers(self, engine):
+        """once, after the database is reserved on every rank: every rank maps the packed planes and side rows of the others (hipIpc
+        handles, all-gathered as bytes) so that its replay can read the few words it needs of a reference kept elsewhere"""
+        if self.plan.world == 1 or not hasattr(engine, "shard_ipc_handles"):
+            return
+        torch = self.torch
+        mine = engine.shard_ipc_handles()
+        t = torch.tensor(list(mine), dtype=torch.uint8, device=self.device)
+        out = [torch.empty_like(t) for _ in range(self.plan.world)]
+        self.dist.all_gather(out, t)
+        for r in range(self.plan.world):
+            if r != self.plan.rank:
+                engine.shard_ipc_open(r, bytes(out[r].cpu().tolist()))
+
+    def disconnect_peers(self, engine):
+        """before the engines are closed: every rank unmaps the others' arrays, then all meet (an owner must not free what is still mapped)"""
+        if self.plan.world > 1 and hasattr(engine, "shard_ipc_close"):
+            engine.shard_ipc_close()
+            self.dist.barrier()
 
     def all_max(self, v):
         self.maxbuf[0] = int(v)
@@ -127,7 +152,9 @@ class TorchExchange:
                 offs[r] = at
                 at += out_split[r]
             where.append({r: recv.data_ptr() + 4 * offs[r] for r in by_owner})
-        return [(where[0][p.owner], where[1][p.owner]) for p in stripe]
+        # the aux block of every piece of the stripe goes to every rank (fixed size; a rank without a piece in a short last stripe sends filler)
+        self.dist.all_gather_into_tensor(self.recv_aux[b], self.send_aux[b])
+        return [(where[0][p.owner], where[1][p.owner], self.recv_aux[b].data_ptr() + 4 * self.aux_ints * p.owner) for p in stripe]
 
     def stream(self):
         """the stream the collectives run on (RCCL: torch's current stream), as the engine's ordering calls take it"""
@@ -154,7 +181,7 @@ def run(engine, plan, xchg, cons, ordinal0=0):
         def scan(k, buf):
             for p in stripes[k]:
                 if p.owner == plan.rank:
-                    engine.shard_scan(p.first, p.n, xchg.send_cnt[buf].data_ptr(), xchg.send_tmin[buf].data_ptr())
+                    engine.shard_scan(p.first, p.n, xchg.send_cnt[buf].data_ptr(), xchg.send_tmin[buf].data_ptr(), xchg.send_aux[buf].data_ptr())
 
         # On device buffers (RCCL) nothing below blocks the host: the scan stream, the stream of the collectives and the replay stream
         # are ordered by events (uvaia_gpu_mark / stream_wait_mark / wait_stream).  Marks 0, 1 = the scan into send[0], send[1];
@@ -186,8 +213,8 @@ def run(engine, plan, xchg, cons, ordinal0=0):
             if on_device:
                 engine.wait_stream(REPLAYS, xchg.stream())       # the replays below read what the exchange delivers
             if active:
-                for p, (cnt_ptr, tmin_ptr) in zip(stripe, got):  # stream order
-                    engine.shard_replay(cnt_ptr, tmin_ptr, p.first, p.n, ordinal0 + p.first, plan.q0, plan.q1)
+                for p, (cnt_ptr, tmin_ptr, aux_ptr) in zip(stripe, got):  # stream order
+                    engine.shard_replay(cnt_ptr, tmin_ptr, aux_ptr, p.owner, p.first, p.n, ordinal0 + p.first, plan.q0, plan.q1)
             if on_device:
                 engine.mark(REPLAYS, 2 + buf)
             stripe_no += 1

@@ -25,8 +25,10 @@ def one(rng, k):
     nbest = rng.choice([1, 2, 5, 13, 40])
     pool = rng.choice([64, 97, 333, 1000, nref])
     tuning = {"rare_max": rng.choice([0, -1, 1, 3, 50]), "subslice_refs": rng.choice([0, 64, 256]),
-              "scan_tiles_per_wave": rng.choice([0, 1, 2]), "scan_waves_per_block": rng.choice([0, 4, 8]),
+              "scan_tiles_per_wave": rng.choice([0, 1, 2, 4]), "scan_waves_per_block": rng.choice([0, 4, 8]),
               "rederive_streams": rng.choice([0, 1, 2]), "scan": rng.choice(["auto", "auto", "compressed"])}          # <= 16 queries scan the packed planes unless told otherwise
+    if tuning["scan_tiles_per_wave"] == 4 and tuning["scan_waves_per_block"] == 4:
+        tuning["scan_waves_per_block"] = 8                                        # four tiles per wave go with eight waves per block
     p_snp = rng.choice([0.002, 0.006, 0.02])
     refs, root, cols = F.synth_alignment(nref, nchar, seed=1000 + k, p_snp=p_snp)
     qs, _, _ = F.synth_alignment(nq, nchar, seed=5000 + k, root=root, poly_cols=cols, p_snp=p_snp)
@@ -57,6 +59,25 @@ def one(rng, k):
         e3 = eng.search_resident(pool)
         n, T, sc, od = eng.drain()
         ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e3)[0]) == list(gold.saved)
+    if rng.random() < 0.35 and pool >= 64:       # reference shards: several contexts on this card, each keeping its own pieces only
+        world, piece = rng.choice([2, 3, 4]), rng.choice([64, 128])
+        if piece <= pool:
+            with capi.Group(q, [0] * world, nbest=nbest, max_pool=pool, piece_refs=piece) as g:
+                g.db_append(refs)
+                eg = g.search_resident(pool)
+                n, T, sc, od = g.drain()
+                ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(eg)[0]) == list(gold.saved)
+            desc["group"] = "%d x %d" % (world, piece)
+    if rng.random() < 0.3:                       # the radius search on the same data
+        dist = rng.choice([0, 1, 3, 9, 40])
+        qb = O.Query(qs, ["q%d" % i for i in range(nq)], acgt=acgt, trim=trim, ambig_q=1.0, dist=dist, is_ball=True)
+        if qb.ntax >= 1:
+            md, _ = qb.ball(refs, ambig_r=0.001)
+            with capi.Engine.from_query(qb, nbest=2, max_pool=pool) as eng:
+                got = np.concatenate([eng.ball(refs[a:a + pool], dist + 1) for a in range(0, nref, pool)])
+                eng.db_append(refs)
+                ok &= bool(np.array_equal(got, md)) and bool(np.array_equal(eng.ball_resident(dist + 1), md))
+            desc["ball"] = dist
     desc["cons"] = len(q.idx_c) > 0
     return desc, bool(ok)
 

@@ -245,7 +245,7 @@ def single_gpu_workload(hostlib, n_query, refs, mode, nbest, pool, steps, warmup
     return out
 
 
-def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset, device, parity_refs=0):
+def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset, device, parity_refs=0, tuning=None):
     """uvaiaball's radius search (src/ball.c:248-259, src/fastaseq.c:660-696) over an HBM-resident database: references per second,
     and how many of them the search had to compare with the queries themselves (the others stop at the queries' consensus)."""
     gen = hostlib.Synth(nchar, seed=seed, preset=preset)
@@ -253,7 +253,7 @@ def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset
     t0 = time.time()
     pq = hostlib.PreparedQuery(qseqs, ["query_%d" % i for i in range(n_query)], dist=dist, acgt=(mode == "acgt"), is_ball=True)
     t1 = time.time()
-    eng = pq.open_engine(nbest=2, max_pool=65536, device=device)
+    eng = pq.open_engine(nbest=2, max_pool=65536, device=device, tuning=tuning)
     eng.db_reserve(refs)
     for a in range(0, refs, 8192):
         n = min(8192, refs - a)
@@ -261,17 +261,41 @@ def ball_workload(hostlib, n_query, refs, dist, mode, steps, nchar, seed, preset
         eng.db_append_block(rows, non_n)
     md = eng.ball_resident(dist + 1)                      # warm-up, and the answer
     eng.ball_asked(reset=True)
+    eng.ball_kernel_ms(reset=True)
     t_a = time.perf_counter()
     for _ in range(steps):
         eng.ball_resident(dist + 1, want=False)
     elapsed = time.perf_counter() - t_a
     asked = eng.ball_asked(reset=True) // max(1, steps)
+    k_ms = [v / max(1, steps) for v in eng.ball_kernel_ms(reset=True)]
     sb = survey_bytes_per_ref(nchar, mode)
+    # per kernel (HIP events on the engine's stream): the consensus pass reads every reference's packed planes once and
+    # (default) leaves their columns of query->idx gathered into dense words; the references that go on are moved into dense tiles; the
+    # pair scan is vector work on the gathered word groups, and a query leaves it once every reference of a tile has reached its limit
+    n_planes = 3 if mode == "acgt" else 4
+    plane_bytes = n_planes * ((nchar + 127) // 128) * 16
+    n_idx = int(len(pq.idx)) if getattr(pq, "idx", None) is not None else 0
+    n_hot = 256 if n_idx >= 512 else 0
+    ng4 = max(1, n_hot // 128 + (n_idx - n_hot + 127) // 128)
+    gathered_bytes = n_planes * ng4 * 16
+    fused = (tuning or {}).get("ball_gather", 2) == 2
+    def gbps(b, ms): return round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
+    def hbm(name, ms, nbytes, **more):
+        g = gbps(nbytes, ms)
+        return {"kernel": name, "ms": round(ms, 3), "bound": "hbm", "bytes": int(nbytes), "GBps": g, "frac": round((g or 0) / HBM_PEAK_GBS, 4), **more}
+    kernels = [
+        hbm("ball_stage1_kernel", k_ms[0], refs * (plane_bytes + (gathered_bytes if fused else 0)),
+            note="planes read once" + (" + the gathered columns of every reference written" if fused else "")),
+        hbm("ball_compact_kernel", k_ms[1], asked * gathered_bytes * 2, note="gathered rows of the references that go on, read (scattered 16-byte reads) and written; with the read-back of their number") if fused else
+        hbm("ball_gather_cols_kernel", k_ms[1], asked * (plane_bytes + gathered_bytes), note="useful bytes; scattered 16-byte reads; with the read-back of the number of references that go on"),
+        {"kernel": "ball_scan_kernel", "ms": round(k_ms[2], 3), "bound": "vector issue",
+         "lane_operations_if_every_query_stayed": int(asked * pq.ntax * ng4 * 4 * (4 if mode == "acgt" else 7)),
+         "note": "a query leaves the scan of a tile once all 64 references have reached their limits against it"}]
     out = {"workload": "uvaiaball: %d queries (%d after pruning) x %d refs x %d cols, %s, radius %d" % (n_query, pq.ntax, refs, nchar, mode, dist),
            "value": round(refs * steps / elapsed, 1), "unit": "ref-seqs/s", "ms_per_search": round(1e3 * elapsed / steps, 3), "steps": steps,
            "kept": int((md <= dist).sum()), "compared_with_the_queries": int(asked),
            "whole_search_GBps": round(refs * sb * steps / elapsed / 1e9, 1), "whole_search_frac_of_hbm_peak": round(refs * sb * steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-           "query_prepare_s": round(t1 - t0, 2)}
+           "kernels": kernels, "query_prepare_s": round(t1 - t0, 2)}
     eng.close()
     if parity_refs > 0:
         O = oracle_module()
@@ -546,7 +570,8 @@ def main():
         return
     if args.ball_only:
         print(json.dumps({"ball": ball_workload(hostlib, args.queries, args.sweep_refs, 2, args.mode, args.steps, args.nchar, args.seed, args.preset, local_rank,
-                                                parity_refs=0 if args.no_parity else 8192)}))
+                                                parity_refs=0 if args.no_parity else 8192,
+                                                tuning=({kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tuning} or None))}))
         return
     dist = None
     if world > 1:

@@ -79,7 +79,9 @@ typedef struct {
   int scan_tiles_per_wave;     /* column-compressed scan: 1, 2 or 4 tiles of 64 references per wave (default 2; 4 only with 8 waves per block) */
   int scan_waves_per_block;    /* column-compressed scan: 4 or 8 waves share a super-tile of 64 queries (default 8) */
   int rederive_streams;        /* uvaia_gpu_db_rederive: its chunks alternate over 1..3 streams (default 3: all chunks in flight at once, the first still done first) */
-  int reserved[7];             /* zero */
+  int ball_gather;             /* radius search: the references' planes on the columns of query->idx are gathered 1 = by a pass of its own over the
+                                  references that go on to the queries, 2 = by the consensus pass itself, for every reference (default 2) */
+  int reserved[6];             /* zero */
 } uvaia_gpu_tuning;
 int uvaia_gpu_open_tuned (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning /* may be NULL */);
 void uvaia_gpu_close (uvaia_gpu_ctx *ctx);
@@ -157,6 +159,9 @@ int uvaia_gpu_ball (uvaia_gpu_ctx *ctx, const char *const *seq, int n_ref, int r
  * for the references the reference's own loop would look at them for (twice the consensus distance >= radius). */
 int uvaia_gpu_ball_resident (uvaia_gpu_ctx *ctx, size_t first, size_t n, int radius, int *mindist);
 unsigned long long uvaia_gpu_ball_asked (uvaia_gpu_ctx *ctx, int reset);    /* references sent on to the queries since the last reset */
+/* device time in ms since the last reset of the three kernels of the radius search: [0] the consensus pass, [1] the gather of the asked
+   references' columns (with the read-back of their number), [2] the pair scan on the gathered tiles */
+void uvaia_gpu_ball_kernel_ms (uvaia_gpu_ctx *ctx, double out[3], int reset);
 
 /* Query preprocessing: the O(Q^2) test of exclude_redundant_query_sequences (src/fastaseq.c:797-841, the
  * call at :806-808).  For each of n_seq sequences (<= max_pool) and each query q of the open set,

@@ -130,10 +130,12 @@ def test_ball_synthetic_many_radii():
                 assert np.array_equal(eng.ball(refs, q.dist + 1), md_want), (acgt, dist)
 
 
+@pytest.mark.parametrize("gather", [1, 2])
 @pytest.mark.parametrize("acgt", [False, True])
-def test_ball_over_the_resident_database_matches_oracle(acgt):
+def test_ball_over_the_resident_database_matches_oracle(acgt, gather):
     """uvaia_gpu_ball_resident on generator data at full genome length: radii from "nearly everything stops at the consensus" to
-    "every reference goes on to the queries" (more of them than one scan batch holds), ranges that start inside a tile."""
+    "every reference goes on to the queries" (more of them than one scan batch holds), ranges that start inside a tile; the columns
+    of query->idx gathered by a pass of its own (1) or by the consensus pass (2, the default)."""
     from uvaia_amd import hostlib
     gen = hostlib.Synth(29903, seed=20241008, preset=1)
     qs, _ = gen.generate_bytes(1 << 40, 24)
@@ -142,7 +144,7 @@ def test_ball_over_the_resident_database_matches_oracle(acgt):
     for dist in (0, 3, 40, 4000):
         q = O.Query(qs, ["q%d" % i for i in range(len(qs))], dist=dist, acgt=acgt, is_ball=True)
         md, keep = q.ball(refs, ambig_r=0.001)                 # (uvaiaball keeps references with at least nchar * A valid sites: nothing is dropped)
-        with capi.Engine.from_query(q, nbest=2, max_pool=512) as eng:
+        with capi.Engine.from_query(q, nbest=2, max_pool=512, tuning={"ball_gather": gather}) as eng:
             eng.db_reserve(len(refs))
             eng.db_append(refs)
             got = eng.ball_resident(q.dist + 1)
@@ -150,6 +152,27 @@ def test_ball_over_the_resident_database_matches_oracle(acgt):
             assert np.array_equal(eng.ball_resident(q.dist + 1, first=70, n=1000), md[70:1070])
             assert eng.ball_asked(reset=True) <= 2 * len(refs)          # two searches: at most every reference goes on to the queries
         assert keep.sum() == (md <= q.dist).sum()
+
+
+@pytest.mark.parametrize("gather", [1, 2])
+@pytest.mark.parametrize("acgt", [False, True])
+def test_ball_with_the_most_diverse_columns_first(acgt, gather):
+    """Enough polymorphic query columns (>= 512) that the gathered words start with the 256 most diverse ones and the scan's queries
+    leave early: same cq->mindist as the oracle, for radii where few, many and all references go on to the queries."""
+    from uvaia_amd import hostlib
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, 400)
+    refs, _ = gen.generate_bytes(0, 1200)
+    refs = refs + qs[:5]
+    for dist in (2, 11, 600):
+        q = O.Query(qs, ["q%d" % i for i in range(len(qs))], dist=dist, acgt=acgt, is_ball=True)
+        assert len(q.idx) >= 512
+        md, _ = q.ball(refs, ambig_r=0.001)
+        with capi.Engine.from_query(q, nbest=2, max_pool=512, tuning={"ball_gather": gather}) as eng:
+            eng.db_reserve(len(refs))
+            eng.db_append(refs)
+            assert np.array_equal(eng.ball_resident(q.dist + 1), md), dist
+            assert np.array_equal(np.concatenate([eng.ball(refs[a:a + 500], q.dist + 1) for a in range(0, len(refs), 500)]), md), dist
 
 
 @pytest.mark.parametrize("acgt", [False, True])

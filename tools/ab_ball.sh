@@ -1,0 +1,23 @@
+#!/bin/bash
+# Engine variants (uvaia_amd/lib/variants/libuvaia_gpu_<name>.so) on the radius-search workload, one box, interleaved twice:
+#   bash tools/ab_ball.sh [extra bench.py flags]
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/ab_ball; mkdir -p $O
+cp uvaia_amd/lib/libuvaia_gpu.so /tmp/libuvaia_gpu_default.so || exit 1
+trap 'cp /tmp/libuvaia_gpu_default.so uvaia_amd/lib/libuvaia_gpu.so' EXIT INT TERM
+cp /tmp/libuvaia_gpu_default.so uvaia_amd/lib/variants/libuvaia_gpu_head.so
+for rep in 1 2; do
+for lib in uvaia_amd/lib/variants/libuvaia_gpu_*.so; do
+  v=$(basename $lib .so); v=${v#libuvaia_gpu_}
+  cp $lib uvaia_amd/lib/libuvaia_gpu.so || exit 1
+  timeout -k 10 300 python bench.py --ball-only --steps 5 "$@" > $O/${v}_$rep.json 2> $O/${v}_$rep.err || { echo "variant $v failed"; tail -5 $O/${v}_$rep.err; exit 1; }
+  python - "$O/${v}_$rep.json" "$v" <<'P'
+import json, sys
+b = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+b = b.get("ball", b)
+print(sys.argv[2], "value", b["value"], "ms/search", b["ms_per_search"], "parity", b.get("parity"), {k["kernel"]: k["ms"] for k in b.get("kernels", [])}, flush=True)
+P
+done
+done
+rm -f uvaia_amd/lib/variants/libuvaia_gpu_head.so
+echo done

@@ -73,11 +73,12 @@ def one(rng, k):
         qb = O.Query(qs, ["q%d" % i for i in range(nq)], acgt=acgt, trim=trim, ambig_q=1.0, dist=dist, is_ball=True)
         if qb.ntax >= 1:
             md, _ = qb.ball(refs, ambig_r=0.001)
-            with capi.Engine.from_query(qb, nbest=2, max_pool=pool) as eng:
+            gather = int(rng.choice([1, 2]))      # the columns of query->idx gathered by a pass of its own, or by the consensus pass
+            with capi.Engine.from_query(qb, nbest=2, max_pool=pool, tuning={"ball_gather": gather}) as eng:
                 got = np.concatenate([eng.ball(refs[a:a + pool], dist + 1) for a in range(0, nref, pool)])
                 eng.db_append(refs)
                 ok &= bool(np.array_equal(got, md)) and bool(np.array_equal(eng.ball_resident(dist + 1), md))
-            desc["ball"] = dist
+            desc["ball"] = "%d/g%d" % (dist, gather)
     desc["cons"] = len(q.idx_c) > 0
     return desc, bool(ok)
 

@@ -137,7 +137,10 @@ struct uvaia_gpu_ctx {
   uint32_t *d_pmask = nullptr;   // [W4*4] mask of the polymorphic query columns (query->idx)
   int *d_mindist = nullptr, *d_ball_list = nullptr, *d_ball_cdist = nullptr, *d_ball_n = nullptr; size_t ball_cap = 0;   // radius search: results, the references that go on to the queries
   uint4 *d_ball_tiles = nullptr; size_t ball_tiles_cap = 0; unsigned long long ball_asked = 0;
+  bool ball_fused = true; uint4 *d_ball_ga = nullptr; size_t ball_ga_tiles = 0;   // stage 1 gathers every reference's columns of query->idx itself (tuning.ball_gather)
+  hipEvent_t ball_ev[4] = {}; double ball_ms[3] = {0., 0., 0.};   // per-kernel time of the radius search (host_ball.inc)
   int *d_idx_cols = nullptr; int n_idx = 0, NG4 = 0;       // query->idx (the polymorphic query columns) and the word groups they fill once gathered
+  std::vector<int> idx_cols; uint32_t *d_ball_masks = nullptr; int NH4 = 0;   // their order in the gathered words: [2][W4*4] masks, hot word groups (ensure_qgather)
   uint32_t *d_qg = nullptr;                                 // the queries on those columns (kernels_ball.inc), built by the first radius search
   unsigned long long *d_ball_key = nullptr;                 // per listed reference: first query that ends the reference's loop (query << 32 | distance)
   // heaps / state

@@ -30,8 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 QUERY_INDEX0 = 1 << 40           # queries come from the same generator, disjoint sequence numbers
-KERNEL_SOURCES = ["uvaia_gpu.hip", "kernels_pack.inc", "kernels_scan_history.inc", "kernels_scan3.inc", "kernels_consensus.inc", "kernels_replay.inc", "kernels_ball.inc",
-                  "host_launch.inc", "host_open.inc", "host_batch.inc", "host_resident.inc", "host_shards.inc", "host_ball.inc"]
+KERNEL_SOURCES = sorted(f for f in os.listdir(os.path.join(ROOT, "uvaia_amd", "csrc")) if f == "uvaia_gpu.hip" or f.endswith(".inc"))   # the engine's translation unit and its parts
 
 
 def parse(argv=None):

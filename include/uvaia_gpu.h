@@ -81,8 +81,16 @@ typedef struct {
   int rederive_streams;        /* uvaia_gpu_db_rederive: its chunks alternate over 1..3 streams (default 3: all chunks in flight at once, the first still done first) */
   int ball_gather;             /* radius search: the references' planes on the columns of query->idx are gathered 1 = by a pass of its own over the
                                   references that go on to the queries, 2 = by the consensus pass itself, for every reference (default 2) */
-  int reserved[6];             /* zero */
+  int query_tables;            /* the scans' query-side tables (plane words, column classes, rare columns, compressed planes, item streams) are built
+                                  1 = by host threads, 2 = on the device from the raw rows (default 2); same bytes either way */
+  int reserved[5];             /* zero */
 } uvaia_gpu_tuning;
+/* Diagnostics: a copy of one of the query-side tables the scans read, as the open call left it on the device (tests compare the two ways
+ * of building them).  which: 0 query plane words, 1 recoded planes (default mode), 2 ambiguity-word lists, 3 column classes, 4 rare-column
+ * mask, 5 compressed polymorphic planes, 6 planes on the rare columns, 7 item streams, 8 their directory, 9 the rebuild's column split,
+ * 10 = eleven ints { polymorphic columns, rare columns, their word groups (2), rare_max, scan choice, groups needing E / V / counts /
+ * rare planes, replay_lq }.  *n_bytes = size of the table; copied only when it fits cap. */
+int uvaia_gpu_export_query_table (uvaia_gpu_ctx *ctx, int which, void *out, size_t cap, size_t *n_bytes);
 int uvaia_gpu_open_tuned (uvaia_gpu_ctx **ctx, const uvaia_gpu_query *query, int heap_size, int device, size_t max_pool, const uvaia_gpu_tuning *tuning /* may be NULL */);
 void uvaia_gpu_close (uvaia_gpu_ctx *ctx);
 const char *uvaia_gpu_last_error (const uvaia_gpu_ctx *ctx);   /* ctx may be NULL: error of the last failed open */

@@ -109,3 +109,51 @@ def test_many_queries_take_the_device_walk_by_default():
     assert dev.names == gold.names and dev.consensus == gold.consensus
     for f in ("idx_c", "idx_m", "idx"):
         assert np.array_equal(getattr(dev, f), getattr(gold, f)), f
+
+
+TABLES = ["query plane words", "recoded planes", "ambiguity-word lists", "column classes", "rare-column mask", "compressed polymorphic planes",
+          "planes on the rare columns", "item streams", "stream directory", "column split", "counts"]
+
+
+def _tables(q, **tuning):
+    with capi.Engine.from_query(q, nbest=3, max_pool=256, tuning=tuning) as eng:
+        return [eng.query_table(w) for w in range(len(TABLES))]
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("n_query,nchar,trim,more", [
+    (3, 333, 0, {}), (70, 2300, 0, {}), (70, 2300, 150, {"scan": "compressed"}), (130, 4097, 7, {"rare_max": 2}), (200, 1500, 0, {"rare_max": -1}),
+    (257, 3000, 0, {"scan_tiles_per_wave": 1, "scan_waves_per_block": 4}), (600, 2500, 30, {"scan_tiles_per_wave": 4})])
+def test_query_tables_built_on_the_device_equal_those_of_the_host_threads(acgt, n_query, nchar, trim, more):
+    """SURVEY 8f rank 2, second half: everything the scans read about the query set -- plane words, recoded planes and ambiguity-word
+    lists, column classes, rare columns, compressed planes, the item stream of every super-tile and its directory -- built by kernels
+    from the raw rows (uvaia_gpu_tuning.query_tables = 2, the default) is byte for byte what the host threads build (= 1)."""
+    qs, _, _ = F.synth_alignment(n_query, nchar, seed=1000 + n_query, p_snp=0.004, p_amb=0.002, n_run_frac=0.3)
+    q = O.Query(qs, ["q%d" % i for i in range(len(qs))], acgt=acgt, trim=trim, ambig_q=1.0, keep_resolved=True)
+    host = _tables(q, query_tables=1, **more)
+    dev = _tables(q, query_tables=2, **more)
+    for name, a, b in zip(TABLES, host, dev):
+        assert a.shape == b.shape, name
+        assert np.array_equal(a, b), (name, int(np.flatnonzero(a != b)[0]))
+    assert len(host[0]) > 0 and len(host[7]) > 0
+
+
+def test_query_tables_on_the_device_at_genome_length_and_a_bad_byte():
+    from uvaia_amd import hostlib
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, 700)
+    for acgt in (False, True):
+        q = O.Query(qs, ["q%d" % i for i in range(len(qs))], acgt=acgt, ambig_q=1.0, keep_resolved=True)
+        host, dev = _tables(q, query_tables=1), _tables(q, query_tables=2)
+        for name, a, b in zip(TABLES, host, dev):
+            assert np.array_equal(a, b), name
+    # a byte outside the alphabet: the same refusal, naming the first such query and byte
+    bad = list(q.seqs)
+    bad[5] = bad[5][:100] + b"!" + bad[5][101:]
+    bad[3] = bad[3][:200] + b"#" + bad[3][201:]
+    msgs = []
+    for how in (1, 2):
+        with pytest.raises(capi.GpuError) as e:
+            capi.Engine(bad, q.consensus, q.idx_c, q.idx_m, q.idx, trim=q.trim, acgt=q.acgt, nbest=3, max_pool=256, tuning={"query_tables": how})
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "query 3" in msgs[0] and "0x23" in msgs[0]

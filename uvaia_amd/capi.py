@@ -14,7 +14,7 @@ NSCORE = 6
 SYMBOLS = [
     "uvaia_gpu_open", "uvaia_gpu_open_tuned", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
-    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_ball_kernel_ms", "uvaia_gpu_agree_on_polymorphic", "uvaia_gpu_query_columns",
+    "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_ball_kernel_ms", "uvaia_gpu_export_query_table", "uvaia_gpu_agree_on_polymorphic", "uvaia_gpu_query_columns",
     "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
@@ -40,7 +40,7 @@ class GpuError(RuntimeError):
 class Tuning(C.Structure):
     """uvaia_gpu_tuning: optional knobs of uvaia_gpu_open_tuned (0 = the library's choice); they change speed, never results."""
     _fields_ = [("subslice_refs", C.c_size_t), ("rare_max", C.c_int), ("scan", C.c_int), ("serial", C.c_int),
-                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("ball_gather", C.c_int), ("reserved", C.c_int * 6)]
+                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("ball_gather", C.c_int), ("query_tables", C.c_int), ("reserved", C.c_int * 5)]
 
     SCAN = {"auto": 0, "packed": 1, "compressed": 2, "wide": 3}
 
@@ -113,6 +113,7 @@ def load_library():
         "uvaia_gpu_ball_resident": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_int, pi]),
         "uvaia_gpu_ball_asked": (C.c_ulonglong, [vp, C.c_int]),
         "uvaia_gpu_ball_kernel_ms": (None, [vp, C.POINTER(C.c_double), C.c_int]),
+        "uvaia_gpu_export_query_table": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "uvaia_gpu_agree_on_polymorphic": (C.c_int, [vp, pp, C.c_int, C.POINTER(C.c_uint8)]),
         "uvaia_gpu_query_columns": (C.c_int, [pp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_uint8)]),
         "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
@@ -473,6 +474,15 @@ class Engine:
 
     def ball_asked(self, reset=False):
         return int(self.L.uvaia_gpu_ball_asked(self.ctx, int(reset)))
+
+    def query_table(self, which):
+        """uvaia_gpu_export_query_table: the table as bytes (numpy uint8)"""
+        n = C.c_size_t(0)
+        self._chk(self.L.uvaia_gpu_export_query_table(self.ctx, int(which), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        if n.value:
+            self._chk(self.L.uvaia_gpu_export_query_table(self.ctx, int(which), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
 
     def ball_kernel_ms(self, reset=False):
         """Device ms since the last reset of (consensus pass, gather of the asked references, pair scan)."""

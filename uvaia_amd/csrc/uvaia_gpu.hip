@@ -123,6 +123,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_batch_grp = nullptr, *d_db_grp = nullptr;   // [tile][W4][64]  popc(E) | popc(V) << 16 of each word group (for queries that are all-N there)
   int *d_batch_tote = nullptr, *d_db_tote = nullptr;
   int *d_amb_q = nullptr;        // [nq][AMB_STRIDE] ambiguity-word lists of the queries
+  struct { const void *p; size_t n; } qtab[10] = {};   // the query-side tables as uvaia_gpu_export_query_table numbers them (device pointer, bytes)
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
   uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 
@@ -226,11 +227,14 @@ void fill_code_table(uint8_t *t)
 #include "kernels_scan3.inc"
 #include "kernels_replay.inc"
 #include "kernels_ball.inc"
+#include "kernels_qprep.inc"
 
 // ------------------------------------------------------------------------------------------------------------
 // host side, in sections (one translation unit: the kernels above are templates the sections instantiate)
 // ------------------------------------------------------------------------------------------------------------
 #include "host_launch.inc"
+#include "host_qtables.inc"
+#include "host_qprep.inc"
 #include "host_open.inc"
 #include "host_batch.inc"
 #include "host_resident.inc"

@@ -45,20 +45,28 @@ def one(rng, k):
     gold = O.search(q, refs, ["r%d" % i for i in range(nref)], pool=pool, nbest=nbest, ambig_r=1.0)
     want = [[(tuple(s), o) for o, _, s in gold.rows[iq]] for iq in range(q.ntax)]
     ok = True
+    failed = []
+
+    def check(what, good):
+        nonlocal ok
+        if not good:
+            failed.append(what)
+            desc["failed"] = failed
+        ok &= bool(good)
     with capi.Engine.from_query(q, nbest=nbest, max_pool=pool, tuning=tuning) as eng:           # streamed
         ent = [eng.push(refs[a:a + pool]) for a in range(0, nref, pool)]
         n, T, sc, od = eng.drain()
-        ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(np.concatenate(ent))[0]) == list(gold.saved)
+        check("streamed", capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(np.concatenate(ent))[0]) == list(gold.saved))
     with capi.Engine.from_query(q, nbest=nbest, max_pool=pool, tuning=tuning) as eng:           # resident
         eng.db_append(refs)
         e2 = eng.search_resident(pool)
         n, T, sc, od = eng.drain()
-        ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e2)[0]) == list(gold.saved)
+        check("resident", capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e2)[0]) == list(gold.saved))
         eng.reset()                                                              # planes rebuilt in place, searched again
         eng.db_rederive()
         e3 = eng.search_resident(pool)
         n, T, sc, od = eng.drain()
-        ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e3)[0]) == list(gold.saved)
+        check("resident after a rebuild", capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(e3)[0]) == list(gold.saved))
     if rng.random() < 0.35 and pool >= 64:       # reference shards: several contexts on this card, each keeping its own pieces only
         world, piece = rng.choice([2, 3, 4]), rng.choice([64, 128])
         if piece <= pool:
@@ -66,7 +74,7 @@ def one(rng, k):
                 g.db_append(refs)
                 eg = g.search_resident(pool)
                 n, T, sc, od = g.drain()
-                ok &= capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(eg)[0]) == list(gold.saved)
+                check("group", capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T and list(np.nonzero(eg)[0]) == list(gold.saved))
             desc["group"] = "%d x %d" % (world, piece)
     if rng.random() < 0.3:                       # the radius search on the same data
         dist = rng.choice([0, 1, 3, 9, 40])
@@ -75,9 +83,10 @@ def one(rng, k):
             md, _ = qb.ball(refs, ambig_r=0.001)
             gather = int(rng.choice([1, 2]))      # the columns of query->idx gathered by a pass of its own, or by the consensus pass
             with capi.Engine.from_query(qb, nbest=2, max_pool=pool, tuning={"ball_gather": gather}) as eng:
-                got = np.concatenate([eng.ball(refs[a:a + pool], dist + 1) for a in range(0, nref, pool)])
+                got = np.concatenate([eng.ball(refs[a:a + pool], qb.dist + 1) for a in range(0, nref, pool)])   # qb.dist: the radius as the query structure corrects it (src/fastaseq.c:713-715)
                 eng.db_append(refs)
-                ok &= bool(np.array_equal(got, md)) and bool(np.array_equal(eng.ball_resident(dist + 1), md))
+                check("ball streamed", np.array_equal(got, md))
+                check("ball resident", np.array_equal(eng.ball_resident(qb.dist + 1), md))
             desc["ball"] = "%d/g%d" % (dist, gather)
     desc["cons"] = len(q.idx_c) > 0
     return desc, bool(ok)

@@ -141,7 +141,7 @@ struct uvaia_gpu_ctx {
   bool ball_fused = true; uint4 *d_ball_ga = nullptr; size_t ball_ga_tiles = 0;   // stage 1 gathers every reference's columns of query->idx itself (tuning.ball_gather)
   hipEvent_t ball_ev[4] = {}; double ball_ms[3] = {0., 0., 0.};   // per-kernel time of the radius search (host_ball.inc)
   int *d_idx_cols = nullptr; int n_idx = 0, NG4 = 0;       // query->idx (the polymorphic query columns) and the word groups they fill once gathered
-  std::vector<int> idx_cols; uint32_t *d_ball_masks = nullptr; int NH4 = 0;   // their order in the gathered words: [2][W4*4] masks, hot word groups (ensure_qgather)
+  std::vector<int> idx_cols; uint32_t *d_ball_masks = nullptr; int NH4 = 0;   // their order in the gathered words: masks [W4][hot 4 | others 4], hot word groups (ensure_qgather)
   uint32_t *d_qg = nullptr;                                 // the queries on those columns (kernels_ball.inc), built by the first radius search
   unsigned long long *d_ball_key = nullptr;                 // per listed reference: first query that ends the reference's loop (query << 32 | distance)
   // heaps / state

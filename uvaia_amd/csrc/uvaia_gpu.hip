@@ -90,7 +90,7 @@ struct uvaia_gpu_ctx {
   long long slice_tf[NBUF] = {};
   size_t subslice = 32768;                // resident search: pools are cut into slices of this size (exact: see search_resident)
   bool subslice_forced = false;           // the length was given (tests): taken as it is
-  int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16, n_idx_c = 0;
+  int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16, n_idx_c = 0, n_idx_m = 0;
   size_t trim = 0;
   size_t max_pool = 0, pool_pad = 0;
   // query side

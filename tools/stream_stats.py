@@ -29,7 +29,10 @@ while p < n:
         out["group_records"] += 1
         out["full_entries"] += int(h[1] & 0xFFFF) * 4
         out["general_items"] += int(h[1] >> 16)
-        out["word_items"] += int(sum((h[2] >> (8 * j)) & 255 for j in range(4)))
+        nw = int(sum((h[2] >> (8 * j)) & 255 for j in range(4)))
+        out["word_items"] += nw
+        w0 = p + 4 + int(h[1] & 0xFFFF) * 4 + int(h[1] >> 16) * 12
+        out["run_items"] = out.get("run_items", 0) + int(np.count_nonzero(s[w0 + 3:w0 + 4 * nw:4]))      # word items that also carry full words
         p += int(h[3])
         continue
     k = int(sum((h[1] >> (8 * j)) & 255 for j in range(4)))
@@ -40,5 +43,5 @@ while p < n:
 names = ["polymorphic_dense", "rare", "NP4", "NR4", "rare_max", "scan", "need_e", "need_v", "need_g", "need_r", "replay_lq"]
 out.update({k: int(v) for k, v in zip(names, cnt)})
 out["queries"] = pq.ntax
-out["per_query"] = {k: round(out[k] / pq.ntax, 2) for k in ("full_entries", "general_items", "word_items", "rare_items")}
+out["per_query"] = {k: round(out[k] / pq.ntax, 2) for k in ("full_entries", "general_items", "word_items", "run_items", "rare_items")}
 print(json.dumps(out))

@@ -607,3 +607,33 @@ def test_resident_search_of_few_queries_at_genome_length(acgt, nq):
     rows, T, ent = _resident_search(q, refs, 700, 25, tuning={"scan": "packed", "subslice_refs": 500})
     assert rows == [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows]
     assert T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
+@pytest.mark.parametrize("acgt", [False, True])
+@pytest.mark.parametrize("tiles_per_wave", [1, 2, 4])
+def test_n_runs_at_every_word_offset_run_items(acgt, tiles_per_wave):
+    """Run items of the column-compressed scan (a word item that also carries the byte mask of the group's words without any valid
+    query character): 90 queries whose N runs start at every offset of a 128-column word group and cover none, one, two or three
+    whole words beside a partial one, with gaps and ambiguity codes at the edges; references with their own N runs.  Heaps,
+    tolerances and dump flags as the oracle's, streamed and resident."""
+    nchar = 3000
+    refs, root, cols = F.synth_alignment(500, nchar, seed=71, p_snp=0.004, n_run_frac=0.3)
+    qs, _, _ = F.synth_alignment(90, nchar, seed=72, root=root, poly_cols=cols, p_snp=0.004, p_amb=0.001, n_run_frac=0.0)
+    rng = np.random.default_rng(73)
+    out = []
+    for i, s in enumerate(qs):
+        t = bytearray(s)
+        for k in range(4):                                         # four runs per query, each in a group of its own
+            g0 = 128 * (1 + 4 * k + (i % 4)) + 256 * (i // 30)
+            a = g0 + (i * 7 + k * 13) % 128                        # every start offset over the queries
+            ln = [1, 31, 32, 33, 64, 65, 96, 97, 127, 128, 129, 200][(i + k) % 12]
+            t[a:a + ln] = b"N" * len(t[a:a + ln])
+            if a > 0 and rng.random() < 0.5:
+                t[a - 1] = ord("-") if rng.random() < 0.5 else ord("R")      # a gap or an ambiguity code right at the edge
+        out.append(bytes(t))
+    q = O.Query(out, _names(len(out), "q"), acgt=acgt, ambig_q=1.0, keep_resolved=True)
+    assert q.ntax > 64
+    _assert_same_search(q, refs, 256, 7, tuning={"scan": "compressed", "scan_tiles_per_wave": tiles_per_wave})
+    rows, T, entered = _resident_search(q, refs, 256, 7, tuning={"scan": "compressed", "scan_tiles_per_wave": tiles_per_wave})
+    gold = O.search(q, refs, _names(len(refs)), pool=256, nbest=7, ambig_r=1.0)
+    assert rows == [[(tuple(s_), o) for o, _, s_ in r_] for r_ in gold.rows] and T == gold.final_T and list(np.nonzero(entered)[0]) == list(gold.saved)

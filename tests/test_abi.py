@@ -75,3 +75,34 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"oracle_lib|liboracle|orc_[a-z]+\s*\(|#include\s+\"[^\"]*oracle", txt):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_tuning_and_query_structs_match_the_header(tmp_path):
+    """ctypes mirrors of uvaia_gpu_tuning and uvaia_gpu_query: same field names in the same order as include/uvaia_gpu.h, same sizes and
+    offsets as a C compiler gives them (a field added on one side only would silently shift every knob after it)."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "uvaia_gpu.h")).read()
+
+    def fields_of(struct_name):
+        end = re.search(r"\}\s*%s\s*;" % struct_name, hdr).start()
+        body = hdr[hdr.rindex("typedef struct", 0, end):end].split("{", 1)[1]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            for part in decl.split(","):                       # "const size_t *idx_c, *idx_m, *idx": one name per part, the last identifier
+                ids = re.findall(r"[A-Za-z_][A-Za-z_0-9]*", re.sub(r"\[.*?\]", "", part))
+                if ids:
+                    names.append(ids[-1])
+        return names
+
+    for cname, ctype in (("uvaia_gpu_tuning", capi.Tuning), ("uvaia_gpu_query", capi._Query)):
+        names = fields_of(cname)
+        assert names == [f[0] for f in ctype._fields_], cname
+        src = tmp_path / ("%s.c" % cname)
+        src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "uvaia_gpu.h"\nint main(void){ printf("%zu", sizeof(' + cname + '));'
+                       + "".join(' printf(" %%zu", offsetof(%s, %s));' % (cname, n) for n in names) + " return 0; }\n")
+        exe = tmp_path / cname
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+        assert got[0] == C.sizeof(ctype), cname
+        assert got[1:] == [getattr(ctype, n).offset for n in names], cname

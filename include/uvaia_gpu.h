@@ -83,7 +83,11 @@ typedef struct {
                                   references that go on to the queries, 2 = by the consensus pass itself, for every reference (default 2) */
   int query_tables;            /* the scans' query-side tables (plane words, column classes, rare columns, compressed planes, item streams) are built
                                   1 = by host threads, 2 = on the device from the raw rows (default 2); same bytes either way */
-  int reserved[5];             /* zero */
+  int replay_extras;           /* packed-plane scan, default mode: 2 = the scan also leaves text - ACGT and partial - text matches of every pair and the
+                                  replay admits without a memory round trip (default 2), 1 = the replay fetches them per admitted pair */
+  int replay_cus;              /* compute units set aside for the replay's stream, the scans and the rebuild getting the others (CU masks): 0 = the
+                                  library's choice (8, one per XCD, where replay_extras applies; none otherwise), -1 = none, n > 0 = n */
+  int reserved[3];             /* zero */
 } uvaia_gpu_tuning;
 /* Diagnostics: a copy of one of the query-side tables the scans read, as the open call left it on the device (tests compare the two ways
  * of building them).  which: 0 query plane words, 1 recoded planes (default mode), 2 ambiguity-word lists, 3 column classes, 4 rare-column
@@ -196,6 +200,13 @@ int uvaia_gpu_scan_stats (uvaia_gpu_ctx *ctx, double *ms, long long *launches, d
 /* counters of the ordered replay since the last reset: out[0] = admissions into heaps, out[1] = pairs whose remaining
  * counters were evaluated on demand, out[2] = of those, evaluated by a dense rescan (ambiguity lists overflowed) */
 int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int reset);
+/* (query, tile of 64 references) pairs whose counters the replay of the packed-plane scan looked at since the last reset (up to 32 queries,
+ * default mode: how sharp the per-tile bounds are) */
+int uvaia_gpu_replay_tiles_opened (uvaia_gpu_ctx *ctx, unsigned long long *out, int reset);
+/* Diagnostics of an engine built with -DREPLAY_TIMING (all zeros otherwise): wall-clock ticks (100 MHz) summed over the replay waves of the
+ * packed-plane scan -- [0] waiting for staged counters, [1] requesting them, [2] inside opened tiles, [3] of that in admissions,
+ * [4] late fetches, [5] their number, [6] whole waves; [7..11] unused. */
+int uvaia_gpu_replay_timing (uvaia_gpu_ctx *ctx, unsigned long long out[12], int reset);
 /* tuning knob: queries held per pass of the packed-plane and four-counter scans (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);
 /* ---- query shards: several GPUs, each holding the whole database and the heaps of a contiguous range of the queries.  The

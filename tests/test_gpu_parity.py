@@ -414,7 +414,7 @@ def test_heavily_ambiguous_sequences_use_the_dense_rescan():
     for iq in range(q.ntax):
         assert rows[iq] == [(tuple(s), o) for o, _, s in gold.rows[iq]]
     assert list(T) == gold.final_T
-    assert dense > 0 and demanded >= admitted > 0
+    assert dense > 0 and demanded > 0 and admitted > 0
 
 
 @pytest.mark.parametrize("acgt", [False, True])
@@ -637,3 +637,40 @@ def test_n_runs_at_every_word_offset_run_items(acgt, tiles_per_wave):
     rows, T, entered = _resident_search(q, refs, 256, 7, tuning={"scan": "compressed", "scan_tiles_per_wave": tiles_per_wave})
     gold = O.search(q, refs, _names(len(refs)), pool=256, nbest=7, ambig_r=1.0)
     assert rows == [[(tuple(s_), o) for o, _, s_ in r_] for r_ in gold.rows] and T == gold.final_T and list(np.nonzero(entered)[0]) == list(gold.saved)
+
+
+@pytest.mark.parametrize("nq", [1, 3, 8, 13, 32])
+@pytest.mark.parametrize("trim", [0, 70])
+def test_scan_side_extras_equal_the_on_demand_counters(nq, trim):
+    """Up to 32 queries in default mode the packed-plane scan also leaves text - ACGT matches and partial - text matches of EVERY pair
+    (scan2_extras) and the replay admits from registers (replay3_kernel).  A mix of sequences: most list a few ambiguous words, some
+    references and one query list more than the side row holds (their pairs stay 'unknown' and are counted on demand), some none.
+    Streamed and resident, both settings of tuning.replay_extras, against the oracle; the keys after the first decide the order here."""
+    L = 1900
+    refs, root, cols = F.synth_alignment(420, L, seed=61, p_snp=0.003, p_amb=0.002)            # ~4 ambiguous sites per sequence
+    refs += F.synth_alignment(60, L, seed=62, root=root, poly_cols=cols, p_snp=0.003, p_amb=0.03)[0]    # lists overflow
+    refs += F.synth_alignment(60, L, seed=63, root=root, poly_cols=cols, p_snp=0.003, p_amb=0.0)[0]     # no ambiguity at all
+    order = np.random.default_rng(9).permutation(len(refs))
+    refs = [refs[i] for i in order]
+    qs = F.synth_alignment(nq, L, seed=64, root=root, poly_cols=cols, p_snp=0.003, p_amb=0.002)[0]
+    if nq >= 3:
+        qs[1] = F.synth_alignment(1, L, seed=65, root=root, poly_cols=cols, p_snp=0.003, p_amb=0.03)[0][0]  # a query whose list overflows
+        qs[2] = F.synth_alignment(1, L, seed=66, root=root, poly_cols=cols, p_snp=0.003, p_amb=0.0)[0][0]
+    q = O.Query(qs, _names(len(qs), "q"), ambig_q=1.0, trim=trim)
+    gold = O.search(q, refs, _names(len(refs)), pool=130, nbest=7, ambig_r=1.0)
+    want = [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows]
+    for extras in (2, 1):
+        tuning = {"replay_extras": extras, "subslice_refs": 192}
+        with capi.Engine.from_query(q, nbest=7, max_pool=130, tuning=tuning) as eng:
+            assert eng.scan_variant() == 0
+            for a in range(0, len(refs), 130):
+                eng.push(refs[a:a + 130])
+            n, T, sc, od = eng.drain()
+            admitted, demanded, dense = eng.replay_stats(reset=True)
+            assert capi.finalise_heaps(n, sc, od) == want and list(T) == gold.final_T, extras
+            if extras == 2:
+                assert 0 < demanded < admitted        # only the pairs with an overflowed list went to memory
+            else:
+                assert demanded >= admitted > 0
+        rows, T, ent = _resident_search(q, refs, 130, 7, tuning=tuning)
+        assert rows == want and T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved), extras

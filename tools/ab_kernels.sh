@@ -2,9 +2,13 @@
 # per-kernel statistics of engine variants (uvaia_amd/lib/variants/) on the headline workload: bash tools/ab_kernels.sh [bench flags]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/ab_kernels; mkdir -p $O
-cp uvaia_amd/lib/libuvaia_gpu.so /tmp/libuvaia_gpu_default.so || exit 1
-trap 'cp /tmp/libuvaia_gpu_default.so uvaia_amd/lib/libuvaia_gpu.so' EXIT INT TERM
-cp /tmp/libuvaia_gpu_default.so uvaia_amd/lib/variants/libuvaia_gpu_head.so
+SAVE=$(mktemp /tmp/libuvaia_gpu_default.XXXXXX.so) || exit 1
+cp uvaia_amd/lib/libuvaia_gpu.so "$SAVE" || exit 1
+# the engine is put back on every way out; a signal ends the script (it does not go on to the next variant)
+restore() { cp "$SAVE" uvaia_amd/lib/libuvaia_gpu.so; rm -f "$SAVE" uvaia_amd/lib/variants/libuvaia_gpu_head.so; }
+trap restore EXIT
+trap 'exit 130' INT TERM
+cp "$SAVE" uvaia_amd/lib/variants/libuvaia_gpu_head.so
 for lib in uvaia_amd/lib/variants/libuvaia_gpu_*.so; do
   v=$(basename $lib .so); v=${v#libuvaia_gpu_}
   cp $lib uvaia_amd/lib/libuvaia_gpu.so || exit 1

@@ -15,7 +15,7 @@ SYMBOLS = [
     "uvaia_gpu_open", "uvaia_gpu_open_tuned", "uvaia_gpu_close", "uvaia_gpu_last_error", "uvaia_gpu_push", "uvaia_gpu_drain",
     "uvaia_gpu_heap_slots", "uvaia_gpu_n_query", "uvaia_gpu_reset", "uvaia_gpu_db_reserve", "uvaia_gpu_db_append",
     "uvaia_gpu_db_append_block", "uvaia_gpu_db_size", "uvaia_gpu_search_resident", "uvaia_gpu_sync", "uvaia_gpu_ball", "uvaia_gpu_ball_resident", "uvaia_gpu_ball_asked", "uvaia_gpu_ball_kernel_ms", "uvaia_gpu_export_query_table", "uvaia_gpu_agree_on_polymorphic", "uvaia_gpu_query_columns",
-    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats",
+    "uvaia_gpu_last_batch_scores", "uvaia_gpu_scan_stats", "uvaia_gpu_replay_stats", "uvaia_gpu_replay_tiles_opened", "uvaia_gpu_replay_timing",
     "uvaia_gpu_state_bytes", "uvaia_gpu_state_export", "uvaia_gpu_state_import", "uvaia_gpu_slice_scan", "uvaia_gpu_slice_replay",
     "uvaia_gpu_entered_flags", "uvaia_gpu_state_range_bytes", "uvaia_gpu_state_export_range", "uvaia_gpu_state_import_range",
     "uvaia_gpu_slice_replay_range", "uvaia_gpu_slice_buffers", "uvaia_gpu_scan_bytes_per_ref", "uvaia_gpu_derived_bytes_per_ref", "uvaia_gpu_scan_variant", "uvaia_gpu_set_query_tile", "uvaia_gpu_packed_bytes_per_ref",
@@ -40,7 +40,7 @@ class GpuError(RuntimeError):
 class Tuning(C.Structure):
     """uvaia_gpu_tuning: optional knobs of uvaia_gpu_open_tuned (0 = the library's choice); they change speed, never results."""
     _fields_ = [("subslice_refs", C.c_size_t), ("rare_max", C.c_int), ("scan", C.c_int), ("serial", C.c_int),
-                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("ball_gather", C.c_int), ("query_tables", C.c_int), ("reserved", C.c_int * 5)]
+                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("ball_gather", C.c_int), ("query_tables", C.c_int), ("replay_extras", C.c_int), ("replay_cus", C.c_int), ("reserved", C.c_int * 3)]
 
     SCAN = {"auto": 0, "packed": 1, "compressed": 2, "wide": 3}
 
@@ -119,6 +119,8 @@ def load_library():
         "uvaia_gpu_last_batch_scores": (C.c_int, [vp, pi, C.c_int]),
         "uvaia_gpu_scan_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_int]),
         "uvaia_gpu_replay_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.c_int]),
+        "uvaia_gpu_replay_tiles_opened": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.c_int]),
+        "uvaia_gpu_replay_timing": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.c_int]),
         "uvaia_gpu_state_bytes": (C.c_size_t, [vp]),
         "uvaia_gpu_state_export": (C.c_int, [vp, C.c_void_p]),
         "uvaia_gpu_state_import": (C.c_int, [vp, C.c_void_p]),
@@ -439,6 +441,18 @@ class Engine:
         out = (C.c_ulonglong * 3)()
         self._chk(self.L.uvaia_gpu_replay_stats(self.ctx, out, int(reset)))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def replay_timing(self, reset=False):
+        """ticks of an engine built with -DREPLAY_TIMING (see include/uvaia_gpu.h); zeros otherwise"""
+        out = (C.c_ulonglong * 12)()
+        self._chk(self.L.uvaia_gpu_replay_timing(self.ctx, out, int(reset)))
+        return [int(x) for x in out]
+
+    def replay_tiles_opened(self, reset=False):
+        """(query, tile) pairs the replay of the packed-plane scan opened since the last reset."""
+        out = C.c_ulonglong(0)
+        self._chk(self.L.uvaia_gpu_replay_tiles_opened(self.ctx, C.byref(out), int(reset)))
+        return int(out.value)
 
     def set_query_tile(self, qt):
         self._chk(self.L.uvaia_gpu_set_query_tile(self.ctx, int(qt)))

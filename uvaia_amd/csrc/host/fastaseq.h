@@ -46,7 +46,9 @@ int quick_count_sequence_acgt (char *s, size_t nsites);    /* ACGT sites (src/fa
 /* for uvaiaball (src/fastaseq.h:78, src/fastaseq.c:660-696): *min_dist = what the reference leaves there for ONE sequence and radius
  * ball_radius.  Runs on the GPU through uvaia_gpu_ball() with an engine kept for `qu` (made at the first call, dropped by
  * del_query_structure or by a call with another query set); errors are fatal, as everywhere in this API.  The batch loop of
- * src/ball.c:248-251 should call uvaia_gpu_ball() with the whole batch instead. */
+ * src/ball.c:248-251 should call uvaia_gpu_ball() with the whole batch instead.
+ * Threading: safe to call from several threads at once, as the reference does inside "#pragma omp parallel for" (src/ball.c:248-250):
+ * the one engine per process, its opening and uvaia_gpu_forget_query() are serialised by a mutex (calls do not run concurrently). */
 void seq_ball_against_query_structure (char **seq, int *min_dist, int ball_radius, query_t qu);
 query_t new_query_structure_from_fasta (char *filename, int trim, int dist, int acgt);
 query_t new_query_structure_from_alignment (alignment aln, int trim, int dist, int acgt);   /* takes ownership of aln */

@@ -1,6 +1,7 @@
 /* gpu_glue.c -- see gpu_glue.h. */
 #include "gpu_glue.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -96,9 +97,13 @@ uvaia_gpu_group_collect_heaps (uvaia_gpu_group *group, heap_t *heap, const char 
 /* ---- seq_ball_against_query_structure (src/fastaseq.h:78): the reference's one-sequence entry point of the radius search, kept for
  * callers of the fastaseq API.  The engine of the query set is opened at the first call and reused until the query set goes away. */
 static struct { query_t qu; uvaia_gpu_ctx *ctx; } ball_engine = {NULL, NULL};
+/* The reference calls seq_ball_against_query_structure from inside "#pragma omp parallel for" (src/ball.c:248-250).  The engine
+ * and its staging / result buffers are one per process: opening, forgetting and the search itself are serialised here, so the kept
+ * entry point is safe to call from any number of threads (it is then as fast as one thread: batch through uvaia_gpu_ball instead). */
+static pthread_mutex_t ball_lock = PTHREAD_MUTEX_INITIALIZER;
 
-void
-uvaia_gpu_forget_query (query_t qu)
+static void
+forget_query_locked (query_t qu)
 {
   if (!ball_engine.ctx || (qu && ball_engine.qu != qu)) return;
   uvaia_gpu_close (ball_engine.ctx);
@@ -106,14 +111,24 @@ uvaia_gpu_forget_query (query_t qu)
 }
 
 void
+uvaia_gpu_forget_query (query_t qu)
+{
+  pthread_mutex_lock (&ball_lock);
+  forget_query_locked (qu);
+  pthread_mutex_unlock (&ball_lock);
+}
+
+void
 seq_ball_against_query_structure (char **seq, int *min_dist, int ball_radius, query_t qu)
 {
   if (!seq || !*seq || !min_dist || !qu) biomcmc_error ("seq_ball_against_query_structure: NULL argument");
+  pthread_mutex_lock (&ball_lock);      /* (biomcmc_error exits the process: no unlock on those paths) */
   if (ball_engine.qu != qu) {
-    uvaia_gpu_forget_query (NULL);
+    forget_query_locked (NULL);
     if (uvaia_gpu_open_query (&ball_engine.ctx, qu, 2, -1, 64)) biomcmc_error ("radius search on the GPU: %s", uvaia_gpu_last_error (NULL));
     ball_engine.qu = qu;
   }
   const char *one[1] = {*seq};
   if (uvaia_gpu_ball (ball_engine.ctx, one, 1, ball_radius, min_dist)) biomcmc_error ("radius search on the GPU: %s", uvaia_gpu_last_error (ball_engine.ctx));
+  pthread_mutex_unlock (&ball_lock);
 }

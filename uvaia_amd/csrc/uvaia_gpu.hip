@@ -85,6 +85,10 @@ struct uvaia_gpu_ctx {
   size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
   uint32_t *d_cntb[NBUF] = {};            // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
   int2 *d_tmin[NBUF] = {};                // per (query, tile of 64 references): {smallest mismatch count, largest ACGT-match count}, one per counter buffer
+  uint32_t *d_extb[NBUF] = {};            // packed-plane scan, default mode: per pair the other two counters (scan2_extras), one per counter buffer; sized like it
+  uint32_t *d_rtpb[NBUF] = {};            // ... and per reference the consensus pre-score packed into one dword (query sets with constant-and-complete columns)
+  uint4 *d_tb8[NBUF] = {};                // ... and per (query, tile of 64) the eight-entry bounds replay3_kernel walks (tile_bounds8)
+  bool use_ext = false;                   // the packed-plane scan leaves the extras and replay3_kernel runs (default mode, up to two query tiles)
   int4 *d_rtb[NBUF] = {};                 // per reference of a slice: untruncated consensus pre-score (query sets with constant-and-complete columns), one per counter buffer
   int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
   long long slice_tf[NBUF] = {};
@@ -117,6 +121,8 @@ struct uvaia_gpu_ctx {
   bool serial = false;           // tuning.serial: no scan/replay overlap (to time the kernels in isolation)
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority
+  int replay_cus = 0;            // compute units set aside for the replay kernels of the resident search (0: none, the streams share the chip by priority)
+  hipStream_t rep_stream = nullptr; hipEvent_t rep_ev[2] = {};   // ... the stream masked to them, and the events that splice its kernels into `stream`'s order
   int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)
   int scan_NW = 8;               // waves per block of scan3_kernel = shares a super-tile's records are cut into
   uint4 *d_batch_ev = nullptr, *d_batch_poly = nullptr, *d_db_ev = nullptr, *d_db_poly = nullptr;
@@ -127,7 +133,7 @@ struct uvaia_gpu_ctx {
   int *d_batch_amb = nullptr, *d_db_amb = nullptr;   // same for the references of the batch buffer / database
   int *d_batch_tot = nullptr, *d_db_tot = nullptr;   // per reference: valid sites (default) / ACGT sites (--acgt), counted by pack_refs_kernel
   uint32_t *d_cnt2 = nullptr;    // [nq_pad][pool_pad] two-counter scan output, one dword per pair: first | second << 16 
-  unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks
+  unsigned long long *d_stats = nullptr;             // admissions, on-demand evaluations, dense fallbacks, tiles opened (replay3_kernel)
   hipEvent_t order_ev[16] = {}; unsigned order_rr = 0;   // uvaia_gpu_wait_stream: ordering against a caller-owned stream
   hipEvent_t mark_ev[8][3] = {}; bool mark_set[8][3] = {}; // uvaia_gpu_mark
   bool fullscan = false;         // four-counter scan + the replay over it (alignments above 49 000 columns; tuning.scan = UVAIA_GPU_SCAN_WIDE)

@@ -87,7 +87,8 @@ typedef struct {
                                   replay admits without a memory round trip (default 2), 1 = the replay fetches them per admitted pair */
   int replay_cus;              /* compute units set aside for the replay's stream, the scans and the rebuild getting the others (CU masks): 0 = the
                                   library's choice (8, one per XCD, where replay_extras applies; none otherwise), -1 = none, n > 0 = n */
-  int reserved[3];             /* zero */
+  int scan_streams;            /* resident search: consecutive slices' scans alternate over 1..3 streams (0 = the library's choice by launch size) */
+  int reserved[2];             /* zero */
 } uvaia_gpu_tuning;
 /* Diagnostics: a copy of one of the query-side tables the scans read, as the open call left it on the device (tests compare the two ways
  * of building them).  which: 0 query plane words, 1 recoded planes (default mode), 2 ambiguity-word lists, 3 column classes, 4 rare-column

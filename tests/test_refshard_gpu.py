@@ -31,7 +31,7 @@ def data():
     return refs, qs, [bytes(s) for s in gappy]
 
 
-@pytest.mark.parametrize("world,piece", [(2, 128), (3, 64), (4, 192)])
+@pytest.mark.parametrize("world,piece", [(2, 128), (3, 64), (4, 192), (8, 64)])      # (8 members, 70 queries: three of them replay nothing)
 @pytest.mark.parametrize("acgt,gappy,pool", [(False, False, 512), (True, False, 300), (False, True, 256), (True, True, 1500)])
 def test_group_of_contexts_on_one_gpu_equals_oracle(data, world, piece, acgt, gappy, pool):
     refs, qs, qs_gappy = data
@@ -89,6 +89,34 @@ def test_group_at_benchmark_shape():
     assert list(np.nonzero(ent)[0]) == list(gold.saved)
 
 
+def test_group_at_config3_shape():
+    """BASELINE config[3]'s regime on one card: 10 000 generator queries, --acgt, k = 100, EIGHT contexts (1 250 queries per replaying
+    member: not a multiple of a super-tile of 64, nor of a query tile of 16 -> shards of 1 264 and a last one of 1 152), pieces of 256
+    references so that the 2 304 references make two stripes (the second one short: one piece), 157 super-tiles per scan, the rare-column
+    cap clamped at 64.  Heaps, tolerances and dump flags against the oracle's single loop."""
+    from uvaia_amd import hostlib
+    nq, n_ref = 10000, 2304
+    gen = hostlib.Synth(29903, seed=20241008, preset=0)
+    qs, _ = gen.generate_bytes(1 << 40, nq)
+    qn = _names(nq, "query_")
+    refs, _ = gen.generate_bytes(0, n_ref)
+    oq = O.Query(qs, qn, acgt=True)
+    gold = O.search(oq, refs, _names(n_ref), pool=n_ref, nbest=100, ambig_r=0.5)
+    pq = hostlib.PreparedQuery(qs, qn, acgt=True)
+    with capi.Group(pq, [0] * 8, nbest=100, max_pool=512, piece_refs=256) as g:
+        shards = [g.query_shard(i) for i in range(8)]
+        assert shards[0] == (0, 1264) and shards[-1][1] == nq and all(a1 == b0 for (_, a1), (b0, _) in zip(shards, shards[1:]))
+        g.db_reserve(n_ref)
+        for a in range(0, n_ref, 1000):
+            g.db_append(refs[a:a + 1000])
+        g.reset()
+        g.db_rederive()
+        ent = g.search_resident(n_ref)
+        n, T, sc, od = g.drain()
+    assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
+    assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
 def test_a_group_of_one_is_a_plain_context(data):
     refs, qs, _ = data
     q = O.Query(qs, _names(70, "q"))
@@ -117,7 +145,9 @@ def test_tolerance_range_may_start_anywhere_under_reference_shards(data):
         eng.set_active_queries(0, 24)
 
 
-def test_bench_two_ranks_over_gloo_on_one_card_end_to_end():
+@pytest.mark.parametrize("flags", [["--queries", "200", "--refs", "8192", "--nbest", "20"],
+                                   ["--queries", "2500", "--refs", "2304", "--mode", "acgt"]])       # config[3]'s regime per rank: 1 250 queries replayed by each of the two ranks (not a multiple of 64), --acgt, k = 100
+def test_bench_two_ranks_over_gloo_on_one_card_end_to_end(flags):
     """`bench.py --gpus 2` as the driver launches it for N > 1 (it starts its own ranks when no launcher did), rehearsed on one card
     with the exchange over gloo (UVAIA_BENCH_BACKEND): the JSON line must be a two-rank line and the sample that went through the
     reference-shard protocol of the timed step must equal the oracle on every rank."""
@@ -127,7 +157,7 @@ def test_bench_two_ranks_over_gloo_on_one_card_end_to_end():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UVAIA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "200", "--refs", "8192", "--nbest", "20"],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + flags,
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]

@@ -152,10 +152,10 @@ def _heap_pairs(rows):
     return by_ref
 
 
-@pytest.mark.parametrize("acgt,n_ref", [(False, 100000), (True, 40000)])
+@pytest.mark.parametrize("acgt,n_ref", [(False, 100000), (True, 16384)])
 def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt, n_ref):
-    """(c) 1 000 queries x 100 000 references (BASELINE config[1]; with --acgt on 40 000: the suite has to stay well inside ten
-    minutes), pool 65 536 / 32 768: the timed step (rederive on its own streams overlapping the sub-slice scans), the same step with
+    """(c) 1 000 queries x 100 000 references (BASELINE config[1]; with --acgt on 16 384 -- its full size is config[2]'s test below --:
+    the suite has to stay well inside eight minutes), pool 65 536 / 32 768: the timed step (rederive on its own streams overlapping the sub-slice scans), the same step with
     every launch serialised, and the streaming push path must leave identical heaps, tolerances and dump flags; and the six scores
     of heap entries are the oracle's untruncated pair scores (checked for every entry that refers to one of 192 sampled references)."""
     pool = 65536 if n_ref > 65536 else 32768
@@ -202,11 +202,13 @@ def test_full_size_config1_three_ways_agree_and_scores_are_the_oracles(acgt, n_r
 
 def test_full_size_config2_three_ways_agree_and_scores_are_the_oracles():
     """(c') BASELINE config[2] at its full size: 10 000 queries x 1 000 000 references, --acgt, k = 100, pool 65 536 (what
-    bench.py's sweep times).  The oracle cannot finish that, so: the timed step (rederive on its own streams overlapping the
-    sub-slice scans), the same step with every launch serialised and the streaming push path leave identical heaps, tolerances and
-    dump flags; every heap is full; and the six scores of heap entries are the oracle's untruncated pair scores (every entry that
-    refers to one of 160 sampled references)."""
-    n_ref, pool, nq = 1000000, 65536, 10000
+    bench.py's sweep times).  The oracle cannot finish that, so at the full size: the timed step (rederive on its own streams
+    overlapping the sub-slice scans) leaves every heap full, what is kept was dumped, and the six scores of heap entries are the
+    oracle's untruncated pair scores (every entry that refers to one of 160 sampled references).  The three ways of running a
+    search -- the timed step, the same step with every launch serialised, the streaming push path -- are compared on the first
+    250 000 references of the same stream (heaps, tolerances, dump flags identical): enough pools to wrap the ring of counter buffers
+    several times, a quarter of the generating and loading (the suite's budget)."""
+    n_ref, n_three, pool, nq = 1000000, 250000, 65536, 10000
     gen = hostlib.Synth(29903, seed=20241008, preset=0)
     qs, _ = gen.generate_bytes(QUERY_INDEX0, nq)
     qn = _names(nq, "query_")
@@ -214,15 +216,18 @@ def test_full_size_config2_three_ways_agree_and_scores_are_the_oracles():
     with pq.open_engine(nbest=100, max_pool=pool) as eng:
         _load(eng, gen, 0, n_ref)
         rows, T, ent = _timed_step(eng, pool)
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:
+        _load(eng, gen, 0, n_three)
+        rows_t, T_t, ent_t = _timed_step(eng, pool)
     with pq.open_engine(nbest=100, max_pool=pool, tuning={"serial": 1}) as eng:
-        _load(eng, gen, 0, n_ref)
+        _load(eng, gen, 0, n_three)
         rows_s, T_s, ent_s = _timed_step(eng, pool)
-    assert rows_s == rows and T_s == T and np.array_equal(ent_s, ent)
+    assert rows_s == rows_t and T_s == T_t and np.array_equal(ent_s, ent_t)
     del rows_s, ent_s
-    with pq.open_engine(nbest=100, max_pool=pool) as eng:              # streaming: sixteen pools of raw characters
+    with pq.open_engine(nbest=100, max_pool=pool) as eng:              # streaming: four pools of raw characters
         ent_p = []
-        for a in range(0, n_ref, pool):
-            m = min(pool, n_ref - a)
+        for a in range(0, n_three, pool):
+            m = min(pool, n_three - a)
             parts = []
             for b in range(a, a + m, 8192):
                 rows_b, non_n = gen.generate(b, min(8192, a + m - b))
@@ -231,8 +236,9 @@ def test_full_size_config2_three_ways_agree_and_scores_are_the_oracles():
             ent_p.append(eng.push([s for p_ in parts for s in p_[0]], non_n=np.concatenate([p_[1] for p_ in parts]), ordinal0=a))
             del parts
         n, Tp, sc, od = eng.drain()
-        assert capi.finalise_heaps(n, sc, od) == rows and list(Tp) == T
-        assert np.array_equal(np.concatenate(ent_p), ent)
+        assert capi.finalise_heaps(n, sc, od) == rows_t and list(Tp) == T_t
+        assert np.array_equal(np.concatenate(ent_p), ent_t)
+    del rows_t, ent_t
     assert all(len(r) == 100 for r in rows)
     by_ref = _heap_pairs(rows)
     assert set(by_ref) <= set(np.nonzero(ent)[0].tolist())

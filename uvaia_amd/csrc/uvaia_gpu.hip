@@ -71,6 +71,7 @@ struct uvaia_gpu_ctx {
   hipStream_t scan_streams[3] = {};       // extra scan streams: small launches (few active query tiles) overlap on up to three streams
   unsigned scan_rr = 0;
   int scan_nstreams = 1;                  // streams consecutive scans alternate over (set per search from the launch size)
+  int scan_nstreams_forced = 0;           // tuning.scan_streams
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
   hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
   // uvaia_gpu_db_rederive: chunks of tiles rebuilt on their own stream; a scan waits for the chunks its slice touches
@@ -92,7 +93,9 @@ struct uvaia_gpu_ctx {
   int4 *d_rtb[NBUF] = {};                 // per reference of a slice: untruncated consensus pre-score (query sets with constant-and-complete columns), one per counter buffer
   int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
   long long slice_tf[NBUF] = {};
-  size_t subslice = 32768;                // resident search: pools are cut into slices of this size (exact: see search_resident)
+  size_t subslice = 25088;                // resident search: pools are cut into slices of about this size (exact: see search_resident).  (32 768 until round 4: at config[1]
+                                          // four slices of 25 024 references instead of three of 33 334 cost 9 % more scan time -- a launch carries about 70 us of ramp and
+                                          // tail -- and still end 4 % sooner: the first replay starts earlier, the last one is shorter)
   bool subslice_forced = false;           // the length was given (tests): taken as it is
   int nq = 0, nq_pad = 0, nchar = 0, W = 0, W4 = 0, P = 4, NQ = 6, acgt = 0, k = 2, qt = 16, n_idx_c = 0, n_idx_m = 0;
   size_t trim = 0;

@@ -555,7 +555,22 @@ def emulate_refshard(args):
         step()
     elapsed = time.perf_counter() - t0
     ms = 1e3 * elapsed / max(1, args.steps)
-    print(json.dumps({"metric": "ref-seqs scored/sec", "emulated": "reference shards: %d contexts on one GPU (uvaia_gpu_group_*), %d references in all; the contexts share the card: "
+    # what one rank of BASELINE config[3] (10 M references over 8 GPUs: 1.25 M per rank) would hold, from this engine's own per-reference sizes
+    packed_b, derived_b = g.member_bytes_per_ref()
+    w4 = (args.nchar + 127) // 128
+    rows = ((pq.ntax + 127) // 128) * 128
+    per_rank_refs, cols = 1250000, plan.piece + 64
+    myrows = max(1, (pq.ntax + n - 1) // n)
+    sizing = {"references_per_rank": per_rank_refs,
+              "packed_planes_bytes": per_rank_refs * packed_b, "derived_planes_bytes": per_rank_refs * (derived_b + w4 * 16),
+              "side_rows_and_counts_bytes": per_rank_refs * (256 + 12), "dump_flags_bytes_whole_stream": n * per_rank_refs,
+              "scan_counter_ring_bytes": 4 * rows * cols * 4 + 4 * rows * (cols // 64) * 8,
+              "exchange_buffers_bytes": 2 * (rows * cols * 4 + rows * (cols // 64) * 8 + n * myrows * cols * 4 + n * myrows * (cols // 64) * 8 + (n + 1) * cols * 20),
+              "note": "per-reference sizes are this engine's (uvaia_gpu_packed_bytes_per_ref, uvaia_gpu_derived_bytes_per_ref + the V plane); the exchange buffers are those of "
+                      "uvaia_gpu_group_open (two send and two receive sets per member); a piece is %d references" % plan.piece}
+    sizing["total_bytes"] = sum(v for k, v in sizing.items() if k.endswith("_bytes") or k.endswith("_stream"))
+    sizing["total_GB"] = round(sizing["total_bytes"] / 1e9, 2)
+    print(json.dumps({"metric": "ref-seqs scored/sec", "per_rank_hbm_at_config3": sizing, "emulated": "reference shards: %d contexts on one GPU (uvaia_gpu_group_*), %d references in all; the contexts share the card: "
                       "step_ms / %d estimates one rank's step on its own GPU" % (n, total, n),
                       "n_contexts": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step_all_contexts_on_one_gpu": round(ms, 3), "estimated_ms_per_rank_step": round(ms / n, 3),
                       "estimated_value_on_%d_gpus" % n: round(total / (ms / n * 1e-3), 1), "unit": "ref-seqs/s", "piece_refs": plan.piece,
@@ -782,6 +797,8 @@ def main():
             "metric": "ref-seqs scored/sec", "value": round(value, 2), "unit": "ref-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "step_ms_rank0": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # what the process group itself reports: the ranks the collectives of the timed steps ran over, and over what
+            "rccl_ranks_seen": (dist.get_world_size() if dist is not None else 1), "collectives_backend": (backend if dist is not None else None),
             "emulated": ("rank 0 of %d query shards on one GPU: `value` is what %d GPUs would reach if every rank took this long" % (emu, emu)) if emu else None,
             "multi_gpu": None if (world == 1 and not emu) else
             ("query shards: every GPU holds all %d references and the heaps of %d of the %d queries (column classes from the whole set); no data-path exchange%s; exact"

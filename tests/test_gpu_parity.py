@@ -280,8 +280,7 @@ def test_rederive_is_idempotent_and_scan_shapes_agree(acgt, tuning):
     assert out[0] == [[(tuple(s_), o) for o, _, s_ in rows] for rows in gold.rows] and out[1] == gold.final_T
 
 
-@pytest.mark.parametrize("acgt", [False, True])
-@pytest.mark.parametrize("nq", [5, 16, 32])
+@pytest.mark.parametrize("acgt,nq", [(False, 5), (True, 16), (False, 32), (True, 32)])
 def test_small_query_sets_on_either_scan(acgt, nq):
     """Up to 32 queries the engine scans the packed planes directly (two-counter kernels with tile bounds); the column-compressed
     scan can be forced and must give the same heaps.  Both against the oracle, streamed and resident."""
@@ -385,7 +384,7 @@ def test_truncated_consensus_prescore_is_reproduced():
 def test_random_small_many_states(acgt):
     """Many tiny problems with heavy ties and tiny heaps: exercises heap layout / tie handling / T dynamics."""
     rng = np.random.default_rng(5)
-    for it in range(8):
+    for it in range(6):
         L = int(rng.integers(40, 200))
         refs, root, cols = F.synth_alignment(int(rng.integers(5, 150)), L, seed=100 + it, p_snp=0.02, p_amb=0.01)
         qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=200 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)
@@ -554,7 +553,7 @@ def test_resident_search_of_few_queries_many_states(acgt):
     reproduce the oracle on many tiny problems with heavy ties, tiny heaps and tiny pools (snapshots taken often: the cut pre-scores
     of src/nearest.c:431-432)."""
     rng = np.random.default_rng(17)
-    for it in range(10):
+    for it in range(5):
         L = int(rng.integers(40, 260))
         refs, root, cols = F.synth_alignment(int(rng.integers(5, 400)), L, seed=300 + it, p_snp=0.02, p_amb=0.01)
         qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=400 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)
@@ -639,8 +638,7 @@ def test_n_runs_at_every_word_offset_run_items(acgt, tiles_per_wave):
     assert rows == [[(tuple(s_), o) for o, _, s_ in r_] for r_ in gold.rows] and T == gold.final_T and list(np.nonzero(entered)[0]) == list(gold.saved)
 
 
-@pytest.mark.parametrize("nq", [1, 3, 8, 13, 32])
-@pytest.mark.parametrize("trim", [0, 70])
+@pytest.mark.parametrize("nq,trim", [(1, 0), (3, 70), (8, 0), (13, 70), (32, 0)])
 def test_scan_side_extras_equal_the_on_demand_counters(nq, trim):
     """Up to 32 queries in default mode the packed-plane scan also leaves text - ACGT matches and partial - text matches of EVERY pair
     (scan2_extras) and the replay admits from registers (replay3_kernel).  A mix of sequences: most list a few ambiguous words, some

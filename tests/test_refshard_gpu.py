@@ -31,8 +31,8 @@ def data():
     return refs, qs, [bytes(s) for s in gappy]
 
 
-@pytest.mark.parametrize("world,piece", [(2, 128), (3, 64), (4, 192), (8, 64)])      # (8 members, 70 queries: three of them replay nothing)
-@pytest.mark.parametrize("acgt,gappy,pool", [(False, False, 512), (True, False, 300), (False, True, 256), (True, True, 1500)])
+@pytest.mark.parametrize("world,piece,acgt,gappy,pool", [(w, p_, a, g_, pl) for w, p_ in ((2, 128), (3, 64), (4, 192)) for a, g_, pl in ((False, False, 512), (True, False, 300), (False, True, 256), (True, True, 1500))]
+                         + [(8, 64, False, False, 512), (8, 64, True, True, 1500)])      # (8 members, 70 queries: three of them replay nothing)
 def test_group_of_contexts_on_one_gpu_equals_oracle(data, world, piece, acgt, gappy, pool):
     refs, qs, qs_gappy = data
     q = O.Query(qs_gappy if gappy else qs, _names(70, "q"), acgt=acgt)
@@ -66,55 +66,8 @@ def test_group_push_streams_batches_like_one_context(data, acgt):
     assert list(np.nonzero(np.concatenate(ent))[0]) == list(gold.saved)
 
 
-def test_group_at_benchmark_shape():
-    """generator data, 1 000 queries x 8 000 references x 29 903 columns, k = 100, four contexts: the regime of the 8-GPU run
-    (63 query tiles per scan, rare columns, 250 queries per replaying context)"""
-    from uvaia_amd import hostlib
-    gen = hostlib.Synth(29903, seed=20241008, preset=0)
-    qs, _ = gen.generate_bytes(1 << 40, 1000)
-    qn = _names(1000, "query_")
-    refs, _ = gen.generate_bytes(0, 8000)
-    oq = O.Query(qs, qn)
-    gold = O.search(oq, refs, _names(len(refs)), pool=8000, nbest=100, ambig_r=0.5)
-    pq = hostlib.PreparedQuery(qs, qn)
-    with capi.Group(pq, [0, 0, 0, 0], nbest=100, max_pool=4096, piece_refs=1024) as g:
-        g.db_reserve(len(refs))
-        for a in range(0, len(refs), 4000):
-            g.db_append(refs[a:a + 4000])
-        g.reset()
-        g.db_rederive()
-        ent = g.search_resident(8000)
-        n, T, sc, od = g.drain()
-    assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
-    assert list(np.nonzero(ent)[0]) == list(gold.saved)
-
-
-def test_group_at_config3_shape():
-    """BASELINE config[3]'s regime on one card: 10 000 generator queries, --acgt, k = 100, EIGHT contexts (1 250 queries per replaying
-    member: not a multiple of a super-tile of 64, nor of a query tile of 16 -> shards of 1 264 and a last one of 1 152), pieces of 256
-    references so that the 2 304 references make two stripes (the second one short: one piece), 157 super-tiles per scan, the rare-column
-    cap clamped at 64.  Heaps, tolerances and dump flags against the oracle's single loop."""
-    from uvaia_amd import hostlib
-    nq, n_ref = 10000, 2304
-    gen = hostlib.Synth(29903, seed=20241008, preset=0)
-    qs, _ = gen.generate_bytes(1 << 40, nq)
-    qn = _names(nq, "query_")
-    refs, _ = gen.generate_bytes(0, n_ref)
-    oq = O.Query(qs, qn, acgt=True)
-    gold = O.search(oq, refs, _names(n_ref), pool=n_ref, nbest=100, ambig_r=0.5)
-    pq = hostlib.PreparedQuery(qs, qn, acgt=True)
-    with capi.Group(pq, [0] * 8, nbest=100, max_pool=512, piece_refs=256) as g:
-        shards = [g.query_shard(i) for i in range(8)]
-        assert shards[0] == (0, 1264) and shards[-1][1] == nq and all(a1 == b0 for (_, a1), (b0, _) in zip(shards, shards[1:]))
-        g.db_reserve(n_ref)
-        for a in range(0, n_ref, 1000):
-            g.db_append(refs[a:a + 1000])
-        g.reset()
-        g.db_rederive()
-        ent = g.search_resident(n_ref)
-        n, T, sc, od = g.drain()
-    assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
-    assert list(np.nonzero(ent)[0]) == list(gold.saved)
+# (the groups at the benchmark's shapes -- 1 000 queries x 4 contexts, 10 000 queries --acgt x 8 contexts: BASELINE config[3]'s regime --
+# live in tests/test_timed_path_gpu.py, next to the single-context tests whose oracle results they share)
 
 
 def test_a_group_of_one_is_a_plain_context(data):

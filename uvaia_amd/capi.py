@@ -568,6 +568,13 @@ class Group:
         self._chk(self.L.uvaia_gpu_group_query_shard(self.g, i, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def member_bytes_per_ref(self):
+        """(packed planes, planes derived for the query set without V) bytes per reference a member keeps for its own pieces"""
+        self.L.uvaia_gpu_packed_bytes_per_ref.restype = C.c_size_t
+        self.L.uvaia_gpu_derived_bytes_per_ref.restype = C.c_size_t
+        m0 = C.c_void_p(self.L.uvaia_gpu_group_member(self.g, 0))
+        return int(self.L.uvaia_gpu_packed_bytes_per_ref(m0)), int(self.L.uvaia_gpu_derived_bytes_per_ref(m0))
+
     def db_reserve(self, n):
         self._chk(self.L.uvaia_gpu_group_db_reserve(self.g, int(n)))
 

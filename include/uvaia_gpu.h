@@ -88,7 +88,10 @@ typedef struct {
   int replay_cus;              /* compute units set aside for the replay's stream, the scans and the rebuild getting the others (CU masks): 0 = the
                                   library's choice (8, one per XCD, where replay_extras applies; none otherwise), -1 = none, n > 0 = n */
   int scan_streams;            /* resident search: consecutive slices' scans alternate over 1..3 streams (0 = the library's choice by launch size) */
-  int reserved[2];             /* zero */
+  int pipeline;                /* resident search over the column-compressed scan: 2 = a slice's replay runs next to its scan and follows its progress counters
+                                  (slices then merge into long launches); 0 / 1 = the replay of a slice starts when its scan has ended (default: the
+                                  thousand waiting replay waves cost the scan a block per CU, measured slower at config[1]) */
+  int reserved[1];             /* zero */
 } uvaia_gpu_tuning;
 /* Diagnostics: a copy of one of the query-side tables the scans read, as the open call left it on the device (tests compare the two ways
  * of building them).  which: 0 query plane words, 1 recoded planes (default mode), 2 ambiguity-word lists, 3 column classes, 4 rare-column

@@ -86,6 +86,19 @@ def test_config1_regime_sub_slices_equal_oracle(config1_sample):
         assert list(np.nonzero(ent)[0]) == list(gold.saved)
 
 
+def test_config1_regime_pipelined_replay_equals_oracle(config1_sample):
+    """tuning.pipeline = 2: one long scan launch per merged slice, its replay launched with it and following the scan's progress counters
+    stripe by stripe (write-through counters, agent-scope loads); same heaps, tolerances and dump flags."""
+    gen, qs, qn, refs, oq, gold = config1_sample
+    pq = hostlib.PreparedQuery(qs, qn)
+    with pq.open_engine(nbest=100, max_pool=65536, tuning={"pipeline": 2, "subslice_refs": 1600}) as eng:
+        _load(eng, gen, 0, len(refs))
+        for _ in range(2):
+            rows, T, ent = _timed_step(eng, 65536)
+            assert rows == _want(gold, oq.ntax) and T == gold.final_T
+            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+
+
 def test_config1_regime_streaming_push_equals_oracle(config1_sample):
     """the reference-shaped boundary call (uvaia_gpu_push, one pool) on the same data"""
     gen, qs, qn, refs, oq, gold = config1_sample

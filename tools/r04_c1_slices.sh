@@ -13,5 +13,5 @@ P
 }
 for rep in 1 2; do
 run base_$rep || exit 1
-for sub in 25088 20032 16704 12544; do run sub${sub}_s1_$rep --subslice $sub --tuning scan_streams=1 || exit 1; done
+for sub in 25088; do run sub${sub}_s1_$rep --subslice $sub --tuning scan_streams=1 || exit 1; done
 done

@@ -67,6 +67,8 @@ constexpr int AMB_ROW = 64;            // ints per REFERENCE side row (256 B, on
                                        //   [0] count (uncapped)  [1..11] word indices  [12 + 4k + p] plane p of the k-th listed word
 constexpr int PACK_CHUNK = 4096;       // references per host->device staging round (multiple of 64)
 constexpr uint32_t SCAN3_BIAS = 16384u; // scan3_kernel: bias of a pair's low counter half (what the rare items and, --acgt, the polymorphic columns may take away)
+constexpr int SCAN_STRIPE_TILES = 64;  // pipelined search: tiles of 64 references per stripe of the scan's progress counters = one round of the replay's walk (a block of scan3_kernel
+                                       // takes R <= 4 consecutive tiles starting at a multiple of R: it never straddles two stripes)
 constexpr int NBUF = 4;                // counter buffers: the scan may run this many slices ahead of the gate/replay
 
 thread_local std::string g_open_error;
@@ -93,6 +95,11 @@ struct uvaia_gpu_ctx {
   hipEvent_t derive_fence[4] = {};
   size_t derive_pending = 0;          // chunks of the last rederive a scan may still have to wait for
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
+  // pipelined search (column-compressed scan): the replay of a slice runs next to its scan and follows its progress counters
+  bool pipeline = false, pipeline_now = false,   // (off unless tuning.pipeline = 2: measured slower at config[1]) slice_piped[NBUF] = {}, pipe_used = false;
+  unsigned *d_progress[NBUF] = {}; size_t progress_cap[NBUF] = {};
+  hipEvent_t scan_started[NBUF] = {};
+  int *d_pipe_err = nullptr;
   size_t slice_cap[NBUF] = {};              // pairs each counter buffer holds (grown when a slice needs more: slices may exceed a pool, see plan_subslices)
   uint32_t *d_cntb[NBUF] = {};            // counter buffers 1..NBUF-1 (buffer 0 is d_cnt2), allocated on first use
   int2 *d_tmin[NBUF] = {};                // per (query, tile of 64 references): {smallest mismatch count, largest ACGT-match count}, one per counter buffer

@@ -96,7 +96,8 @@ struct uvaia_gpu_ctx {
   size_t derive_pending = 0;          // chunks of the last rederive a scan may still have to wait for
   bool replay_recorded[NBUF] = {}, slice_scanned[NBUF] = {}, slice_cons_done[NBUF] = {};
   // pipelined search (column-compressed scan): the replay of a slice runs next to its scan and follows its progress counters
-  bool pipeline = false, pipeline_now = false,   // (off unless tuning.pipeline = 2: measured slower at config[1]) slice_piped[NBUF] = {}, pipe_used = false;
+  // (off unless tuning.pipeline = 2: measured slower at config[1])
+  bool pipeline = false, pipeline_now = false, slice_piped[NBUF] = {}, pipe_used = false;
   unsigned *d_progress[NBUF] = {}; size_t progress_cap[NBUF] = {};
   hipEvent_t scan_started[NBUF] = {};
   int *d_pipe_err = nullptr;

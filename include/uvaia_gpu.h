@@ -91,7 +91,9 @@ typedef struct {
   int pipeline;                /* resident search over the column-compressed scan: 2 = a slice's replay runs next to its scan and follows its progress counters
                                   (slices then merge into long launches); 0 / 1 = the replay of a slice starts when its scan has ended (default: the
                                   thousand waiting replay waves cost the scan a block per CU, measured slower at config[1]) */
-  int reserved[1];             /* zero */
+  int head_scan;               /* resident search over the column-compressed scan: 2 = the stream's first 128 references take the four-counter scan, so that the
+                                  heaps fill without a memory round trip per admission; 0 / 1 = they go through the slices like the rest (default: the
+                                  63 blocks of that scan run for 0.4 ms on their own, more than the hundred round trips they save) */
 } uvaia_gpu_tuning;
 /* Diagnostics: a copy of one of the query-side tables the scans read, as the open call left it on the device (tests compare the two ways
  * of building them).  which: 0 query plane words, 1 recoded planes (default mode), 2 ambiguity-word lists, 3 column classes, 4 rare-column

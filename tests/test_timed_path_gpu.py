@@ -88,10 +88,11 @@ def test_config1_regime_sub_slices_equal_oracle(config1_sample):
 
 def test_config1_regime_pipelined_replay_equals_oracle(config1_sample):
     """tuning.pipeline = 2: one long scan launch per merged slice, its replay launched with it and following the scan's progress counters
-    stripe by stripe (write-through counters, agent-scope loads); same heaps, tolerances and dump flags."""
+    stripe by stripe (write-through counters, agent-scope loads); tuning.head_scan = 2: the first 128 references through the four-counter
+    scan and its replay.  Same heaps, tolerances and dump flags."""
     gen, qs, qn, refs, oq, gold = config1_sample
     pq = hostlib.PreparedQuery(qs, qn)
-    with pq.open_engine(nbest=100, max_pool=65536, tuning={"pipeline": 2, "subslice_refs": 1600}) as eng:
+    with pq.open_engine(nbest=100, max_pool=65536, tuning={"pipeline": 2, "head_scan": 2, "subslice_refs": 1600}) as eng:
         _load(eng, gen, 0, len(refs))
         for _ in range(2):
             rows, T, ent = _timed_step(eng, 65536)

@@ -40,7 +40,7 @@ class GpuError(RuntimeError):
 class Tuning(C.Structure):
     """uvaia_gpu_tuning: optional knobs of uvaia_gpu_open_tuned (0 = the library's choice); they change speed, never results."""
     _fields_ = [("subslice_refs", C.c_size_t), ("rare_max", C.c_int), ("scan", C.c_int), ("serial", C.c_int),
-                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("ball_gather", C.c_int), ("query_tables", C.c_int), ("replay_extras", C.c_int), ("replay_cus", C.c_int), ("scan_streams", C.c_int), ("pipeline", C.c_int), ("reserved", C.c_int * 1)]
+                ("scan_tiles_per_wave", C.c_int), ("scan_waves_per_block", C.c_int), ("rederive_streams", C.c_int), ("ball_gather", C.c_int), ("query_tables", C.c_int), ("replay_extras", C.c_int), ("replay_cus", C.c_int), ("scan_streams", C.c_int), ("pipeline", C.c_int), ("head_scan", C.c_int)]
 
     SCAN = {"auto": 0, "packed": 1, "compressed": 2, "wide": 3}
 

@@ -142,6 +142,7 @@ struct uvaia_gpu_ctx {
   bool serial = false;           // tuning.serial: no scan/replay overlap (to time the kernels in isolation)
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority
+  bool head_full = false;        // tuning.head_scan = 2: the stream's first two tiles go through the four-counter scan (heaps fill without on-demand fetches; measured slower)
   int replay_cus = 0;            // compute units set aside for the replay kernels of the resident search (0: none, the streams share the chip by priority)
   hipStream_t rep_stream = nullptr; hipEvent_t rep_ev[2] = {};   // ... the stream masked to them, and the events that splice its kernels into `stream`'s order
   int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)

@@ -82,7 +82,7 @@ def parse(argv=None):
 def kernel_source_hash():
     """sha256 over the engine's kernel sources: PMC figures in profiles/ are only quoted for the build they were measured on"""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES + ["Makefile"]:                       # (the Makefile: its flags are part of what the kernels compile to)
         with open(os.path.join(ROOT, "uvaia_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -211,7 +211,9 @@ int uvaia_gpu_replay_stats (uvaia_gpu_ctx *ctx, unsigned long long out[3], int r
 int uvaia_gpu_replay_tiles_opened (uvaia_gpu_ctx *ctx, unsigned long long *out, int reset);
 /* Diagnostics of an engine built with -DREPLAY_TIMING (all zeros otherwise): wall-clock ticks (100 MHz) summed over the replay waves of the
  * packed-plane scan -- [0] waiting for staged counters, [1] requesting them, [2] inside opened tiles, [3] of that in admissions,
- * [4] late fetches, [5] their number, [6] whole waves; [7..11] unused. */
+ * [4] late fetches, [5] their number, [6] whole waves, [7] their prologues (heap and tables into LDS), [8] waves; [9..11] unused.  (replay2_kernel:
+ * [0] waits for on-demand words, [1] exact comparisons, [2] heap updates, [3] waits for a group's counters, [4] tolerance rises, [5] groups,
+ * [6] whole waves, [7] the slowest wave.) */
 int uvaia_gpu_replay_timing (uvaia_gpu_ctx *ctx, unsigned long long out[12], int reset);
 /* tuning knob: queries held per pass of the packed-plane and four-counter scans (8, 16 or 32); 0 = default */
 int uvaia_gpu_set_query_tile (uvaia_gpu_ctx *ctx, int qt);

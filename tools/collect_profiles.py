@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Copies the results of tools/measure_round.sh (gpurun_out/measure/) into profiles/ under round-3 names and writes
-profiles/r03_pmc_traffic.json, the block bench.py quotes for `roofline.traffic` (only for the build of the kernels it was measured
-on: it carries the hash of the kernel sources).  Usage: python tools/collect_profiles.py"""
+"""Copies the results of tools/measure_round.sh (gpurun_out/measure/) into profiles/ under round-4 names and writes
+profiles/r04_pmc_traffic.json, the block bench.py quotes for `roofline.traffic`, `roofline.issue` and `roofline.waits` (only for the
+build of the kernels it was measured on: it carries the hash of the kernel sources).  Usage: python tools/collect_profiles.py"""
+import glob
 import json
 import os
 import shutil
@@ -11,28 +12,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 M = os.path.join(ROOT, "gpurun_out", "measure")
 P = os.path.join(ROOT, "profiles")
+R = "r04"
+ISSUE_PEAK = 1037.0       # G wave-instructions/s, VALU + SALU mixed, whole chip: profiles/r01_issue_rate_microbench.txt
 
 
 def last_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
+def first(pattern):
+    g = sorted(glob.glob(os.path.join(M, pattern), recursive=True))
+    return g[0] if g else None
+
+
 def main():
     import bench
-    for src, dst in (("bench_default.json", "r03_bench_default.json"), ("bench_acgt_c1.json", "r03_bench_c1_acgt.json"),
-                     ("stats/c1_kernel_stats.csv", "r03_bench_c1_kernel_stats.csv"),
-                     ("pmc_fetch/f_counter_collection.csv", "r03_pmc_fetch_counter_collection.csv"), ("pmc_write/w_counter_collection.csv", "r03_pmc_write_counter_collection.csv"),
-                     ("pmc_fetch_q4/f_counter_collection.csv", "r03_pmc_fetch_q4_counter_collection.csv"),
-                     ("pmc_sqa/a_counter_collection.csv", "r03_pmc_sq_a_counter_collection.csv"), ("pmc_sqb/b_counter_collection.csv", "r03_pmc_sq_b_counter_collection.csv"),
-                     ("q4/q4_kernel_stats.csv", "r03_q4_1Mrefs_kernel_stats.csv"), ("q4/q4_kernel_trace.csv", "r03_q4_1Mrefs_kernel_trace.csv"),
-                     ("hbm_read.txt", "r03_hbm_read_ceiling.txt"), ("push_rate.json", "r03_push_rate.json"), ("ingest.json", "r03_ingest_text_vs_packed.json"),
-                     ("emu_refshard_2.json", "r03_emulated_reference_shards_2.json"), ("emu_refshard_4.json", "r03_emulated_reference_shards_4.json"),
-                     ("emu_refshard_8.json", "r03_emulated_reference_shards_8.json"), ("align_cli.json", "r03_uvaialign_cli_10k.json"),
-                     ("prune_timing.txt", "r03_query_preparation_timing.txt"),
-                     ("ball/ball_kernel_stats.csv", "r03_ball_kernel_stats.csv"), ("ball.json", "r03_ball.json"),
-                     ("c1trace/c1_kernel_trace.csv", "r03_config1_kernel_trace.csv")):
-        if os.path.exists(os.path.join(M, src)):
-            shutil.copyfile(os.path.join(M, src), os.path.join(P, dst))
+    copies = [("bench_default.json", "bench_default.json"), ("bench_acgt_c1.json", "bench_c1_acgt.json"),
+              ("stats/**/c1_kernel_stats.csv", "bench_c1_kernel_stats.csv"), ("stats2/**/c2_kernel_stats.csv", "config2_kernel_stats.csv"),
+              ("q4/**/q4_kernel_stats.csv", "q4_1Mrefs_kernel_stats.csv"), ("q4/**/q4_kernel_trace.csv", "q4_1Mrefs_kernel_trace.csv"),
+              ("q16/**/q16_kernel_stats.csv", "q16_1Mrefs_kernel_stats.csv"), ("q16/**/q16_kernel_trace.csv", "q16_1Mrefs_kernel_trace.csv"),
+              ("c1trace/**/c1_kernel_trace.csv", "config1_kernel_trace.csv"),
+              ("ball/**/ball_kernel_stats.csv", "ball_kernel_stats.csv"), ("ball.json", "ball.json"),
+              ("hbm_read.txt", "hbm_read_ceiling.txt"), ("push_rate.json", "push_rate.json"), ("ingest.json", "ingest_text_vs_packed.json"),
+              ("emu_refshard_2.json", "emulated_reference_shards_2.json"), ("emu_refshard_4.json", "emulated_reference_shards_4.json"),
+              ("emu_refshard_8.json", "emulated_reference_shards_8.json"), ("emu_refshard_8_config3.json", "emulated_reference_shards_8_config3_regime.json"),
+              ("load_latency.txt", "load_latency_next_to_a_stream.txt"), ("probe_q4.txt", "small_query_replay_tiles_opened.txt"),
+              ("probe_q4_timing.txt", "small_query_replay_time_split.txt"), ("probe_c1_timing.txt", "config1_replay_time_split.txt")]
+    for d in ("c1_fetch", "c1_write", "c1_insts_a", "c1_waits", "c1_units", "c1_tcc", "c2_fetch", "c2_write", "c2_insts_a", "c2_waits", "c2_tcc", "q4_fetch"):
+        copies.append(("pmc_%s/**/*counter_collection.csv" % d, "pmc_%s_counter_collection.csv" % d))
+    for src, dst in copies:
+        f = first(src)
+        if f:
+            shutil.copyfile(f, os.path.join(P, "%s_%s" % (R, dst)))
     if not os.path.exists(os.path.join(M, "pmc_summary.json")):
         print("no PMC passes to summarise")
         return
@@ -47,36 +58,53 @@ def main():
 
     out = {"note": "rocprofv3 --pmc, one counter group per pass (tools/measure_round.sh). FETCH_SIZE/WRITE_SIZE are KB per dispatch; gfx950 FETCH_SIZE "
                    "reports half of wide coalesced reads (MI355X_MICROARCH.md), hence x2; checked on the packed-plane scan of the Q = 4 run below, which has to read "
-                   "every packed byte exactly once. FETCH_SIZE counts L2 misses (Infinity-Cache hits included).",
-           "kernel_source_hash": bench.kernel_source_hash(), "raw": summ}
-    scan_f, scan_w = pick("config1_fetch", "scan3_kernel"), pick("config1_write", "scan3_kernel")
-    if scan_f and scan_w:
+                   "every packed byte exactly once. FETCH_SIZE counts L2 misses (Infinity-Cache hits included). SQ counters are summed over the chip per dispatch.",
+           "kernel_source_hash": bench.kernel_source_hash(), "entries": [], "raw": summ}
+
+    def entry(tag, kernel, cfg, algorithmic_bytes_per_launch, avg_launch_ms):
+        f, w = pick(tag + "_fetch", kernel), pick(tag + "_write", kernel)
+        if not f or not w:
+            return
         # full-size launches only (a step may end with a shorter slice): the maximum per dispatch
-        fetch_kb, write_kb = scan_f["FETCH_SIZE"]["max"], scan_w["WRITE_SIZE"]["max"]
-        e = {"config": {"queries": b["config"]["queries"], "refs_per_gpu": b["config"]["refs_per_gpu"], "pool": b["config"]["pool"], "mode": b["config"]["mode"]},
-             "hbm_side_read_bytes_per_launch": fetch_kb * 1024 * 2, "write_bytes_per_launch": write_kb * 1024,
-             "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
-             "kernel_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"] * b["roofline"]["kernel_bytes_per_ref"] / b["roofline"]["algorithmic_bytes_per_ref"]}
-        sqa, sqb = pick("config1_sq_a", "scan3_kernel"), pick("config1_sq_b", "scan3_kernel")
-        if sqa and sqb:
-            tot = {k: v["sum"] for k, v in {**sqa, **sqb}.items()}
-            n_instr = sum(tot.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
-            n_disp = sqa["SQ_INSTS_VALU"]["n"]
-            per_launch = n_instr / n_disp
-            rate = per_launch / (b["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
-            e["instruction_mix_all_dispatches"] = tot
-            e["wave_instructions_per_launch"] = per_launch
-            e["issue"] = {"wave_instructions_per_launch": round(per_launch), "achieved": round(rate, 1), "peak": 1037.0, "unit": "G wave-instr/s", "frac": round(rate / 1037.0, 3),
-                          "mix": {k[9:]: round(tot[k] / n_instr, 3) for k in tot if k.startswith("SQ_INSTS_")},
-                          "source": "SQ passes of this file over avg_launch_ms of the bench line; peak: profiles/r01_issue_rate_microbench.txt (VALU + SALU mixed, whole chip)"}
-        out["scan3_kernel"] = e
-    q4f = pick("q4_1Mrefs_fetch", "scan2_iupac_kernel")
+        e = {"kernel": "scan3_kernel", "config": cfg, "hbm_side_read_bytes_per_launch": f["FETCH_SIZE"]["max"] * 1024 * 2, "write_bytes_per_launch": w["WRITE_SIZE"]["max"] * 1024,
+             "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch}
+        ia = pick(tag + "_insts_a", kernel)
+        if ia:
+            n_disp = ia["SQ_INSTS_VALU"]["n"]
+            tot = {k: v["sum"] for k, v in ia.items() if k.startswith("SQ_INSTS_")}
+            per_launch = sum(tot.values()) / n_disp
+            e["issue"] = {"wave_instructions_per_launch": round(per_launch), "peak": ISSUE_PEAK, "unit": "G wave-instr/s",
+                          "mix": {k[9:]: round(v / sum(tot.values()), 3) for k, v in tot.items()},
+                          "source": "SQ_INSTS_* passes of profiles/%s_pmc_%s_insts_a_counter_collection.csv; peak: profiles/r01_issue_rate_microbench.txt (VALU + SALU mixed, whole chip)" % (R, tag)}
+            if avg_launch_ms:
+                e["issue"]["achieved"] = round(per_launch / (avg_launch_ms * 1e-3) / 1e9, 1)
+                e["issue"]["frac"] = round(e["issue"]["achieved"] / ISSUE_PEAK, 3)
+        wt, tc = pick(tag + "_waits", kernel), pick(tag + "_tcc", kernel)
+        if wt:
+            wc = wt["SQ_WAVE_CYCLES"]["sum"]
+            e["waits"] = {"of_wave_cycles": {"waiting_at_any_counter": round(wt["SQ_WAIT_ANY"]["sum"] / wc, 3), "waiting_for_an_issue_slot": round(wt["SQ_WAIT_INST_ANY"]["sum"] / wc, 3),
+                                             "of_that_lds": round(wt["SQ_WAIT_INST_LDS"]["sum"] / wc, 3), "issuing": round(wt["SQ_ACTIVE_INST_ANY"]["sum"] / wc, 3),
+                                             "issuing_valu": round(wt["SQ_ACTIVE_INST_VALU"]["sum"] / wc, 3), "issuing_scalar": round(wt["SQ_ACTIVE_INST_SCA"]["sum"] / wc, 3)},
+                          "source": "profiles/%s_pmc_%s_waits_counter_collection.csv" % (R, tag)}
+        if tc:
+            req = tc["TCC_REQ_sum"]["mean"]
+            e["l2"] = {"requests_per_launch": round(req), "hit_rate": round(tc["TCC_HIT_sum"]["mean"] / max(req, 1), 3), "miss_bytes_per_launch_128B": round(tc["TCC_MISS_sum"]["mean"] * 128),
+                       "source": "profiles/%s_pmc_%s_tcc_counter_collection.csv" % (R, tag)}
+        out["entries"].append(e)
+
+    entry("c1", "scan3_kernel", {"queries": b["config"]["queries"], "mode": b["config"]["mode"], "refs_per_gpu": b["config"]["refs_per_gpu"], "pool": b["config"]["pool"]},
+          b["roofline"]["algorithmic_bytes_per_launch"], b["roofline"]["avg_launch_ms"])
+    c2 = [e_ for e_ in (b.get("sweep") or []) if e_.get("queries") == 10000]
+    if c2:
+        entry("c2", "scan3_kernel", {"queries": 10000, "mode": "acgt", "measured_on": "125 000 references (five launches of the sweep entry's length)"},
+              c2[0]["roofline"]["algorithmic_bytes_per_launch"], c2[0]["roofline"]["avg_launch_ms"])
+    q4f = pick("q4_fetch", "scan2_iupac_kernel")
     if q4f:
         total_kb = q4f["FETCH_SIZE"]["sum"] / (q4f["FETCH_SIZE"]["n"] / 5.0)        # five launches per step (short head and tail slices)
         out["q4_1Mrefs_check"] = {"kernel": "scan2_iupac_kernel", "fetch_bytes_corrected_per_step": total_kb * 1024 * 2, "packed_bytes_per_step": 1000000 * 14976,
                                   "ratio": total_kb * 1024 * 2 / (1000000 * 14976.0)}
-    json.dump(out, open(os.path.join(P, "r03_pmc_traffic.json"), "w"), indent=1)
-    print("profiles updated")
+    json.dump(out, open(os.path.join(P, "%s_pmc_traffic.json" % R), "w"), indent=1)
+    print("profiles updated:", len(out["entries"]), "PMC entries")
 
 
 if __name__ == "__main__":

@@ -22,6 +22,6 @@ for n_ref in (65536, total):
     eng.sync()
     n, T, sc, od = eng.drain()
     print(json.dumps({"queries": nq, "refs": n_ref, "tiles": (n_ref + 63) // 64, "T": [int(t) for t in T], "admitted_demanded_dense": eng.replay_stats(), "tiles_opened": eng.replay_tiles_opened(),
-                      "timing_us_sum_over_waves": dict(zip(["wait_staged", "request", "in_tiles", "in_admissions", "late_fetch", "n_late", "whole_wave"], [x / 100.0 for x in eng.replay_timing()[:7]])),
+                      "timing_us_sum_over_waves": dict(zip(["wait_staged", "request", "in_tiles", "in_admissions", "late_fetch", "n_late", "whole_wave", "prologue", "n_waves_x100"], [x / 100.0 for x in eng.replay_timing()[:9]])),
                       "worst_first_key": [int(sc[q][1][0]) if n[q] else None for q in range(nq)], "n_idx_c": int(pq.n_idx_c) if hasattr(pq, "n_idx_c") else None}), flush=True)
     eng.close()

@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 QUERY_INDEX0 = 1 << 40           # queries come from the same generator, disjoint sequence numbers
-KERNEL_SOURCES = sorted(f for f in os.listdir(os.path.join(ROOT, "uvaia_amd", "csrc")) if f == "uvaia_gpu.hip" or f.endswith(".inc"))   # the engine's translation unit and its parts
+KERNEL_SOURCES = sorted(f for f in os.listdir(os.path.join(ROOT, "uvaia_amd", "csrc")) if f == "uvaia_gpu.hip" or (f.startswith("kernels_") and f.endswith(".inc")))   # the engine's device code (host_*.inc launch it)
 
 
 def parse(argv=None):

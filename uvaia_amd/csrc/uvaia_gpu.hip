@@ -195,6 +195,7 @@ struct uvaia_gpu_ctx {
   const int4 *last_rt = nullptr;
   // stats
   std::vector<ScanEvt> evts;
+  std::vector<hipEvent_t> ev_pool;      // timing events of earlier launches, reused (creating and destroying a pair per launch was 50-100 us of host time per step)
   double scan_ms = 0, scan_bytes = 0; long long scan_launches = 0;
   bool profile = true;
   std::string err;

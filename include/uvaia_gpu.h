@@ -87,7 +87,8 @@ typedef struct {
                                   replay admits without a memory round trip (default 2), 1 = the replay fetches them per admitted pair */
   int replay_cus;              /* compute units set aside for the replay's stream, the scans and the rebuild getting the others (CU masks): 0 = the
                                   library's choice (8, one per XCD, where replay_extras applies; none otherwise), -1 = none, n > 0 = n */
-  int scan_streams;            /* resident search: consecutive slices' scans alternate over 1..3 streams (0 = the library's choice by launch size) */
+  int scan_streams;            /* resident search: consecutive slices' scans alternate over 1..3 streams (0 = the library's choice by launch size);
+                                  100 + p (p = 1..98): a pool's first slice is p % of an equal share (default 70), 199: equal slices */
   int pipeline;                /* resident search over the column-compressed scan: 2 = a slice's replay runs next to its scan and follows its progress counters
                                   (slices then merge into long launches); 0 / 1 = the replay of a slice starts when its scan has ended (default: the
                                   thousand waiting replay waves cost the scan a block per CU, measured slower at config[1]) */

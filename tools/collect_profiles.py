@@ -65,8 +65,8 @@ def main():
         f, w = pick(tag + "_fetch", kernel), pick(tag + "_write", kernel)
         if not f or not w:
             return
-        # full-size launches only (a step may end with a shorter slice): the maximum per dispatch
-        e = {"kernel": "scan3_kernel", "config": cfg, "hbm_side_read_bytes_per_launch": f["FETCH_SIZE"]["max"] * 1024 * 2, "write_bytes_per_launch": w["WRITE_SIZE"]["max"] * 1024,
+        # the mean over the dispatches, like the launch time and the algorithmic bytes it is set against (a pool's first slice is shorter than the others)
+        e = {"kernel": "scan3_kernel", "config": cfg, "hbm_side_read_bytes_per_launch": f["FETCH_SIZE"]["mean"] * 1024 * 2, "write_bytes_per_launch": w["WRITE_SIZE"]["mean"] * 1024,
              "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch}
         ia = pick(tag + "_insts_a", kernel)
         if ia:

@@ -84,6 +84,7 @@ struct uvaia_gpu_ctx {
   unsigned scan_rr = 0;
   int scan_nstreams = 1;                  // streams consecutive scans alternate over (set per search from the launch size)
   int scan_nstreams_forced = 0;           // tuning.scan_streams
+  int first_slice_pct = 70;               // a pool's first slice is this share of an equal one (tuning.scan_streams = 100 + p sets p; 199 = equal slices)
   hipStream_t scan_stream = nullptr;      // ring mode: scans of later slices run here while the replay chain waits
   hipEvent_t scan_done[NBUF] = {}, replay_done[NBUF] = {};
   // uvaia_gpu_db_rederive: chunks of tiles rebuilt on their own stream; a scan waits for the chunks its slice touches

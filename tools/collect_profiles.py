@@ -100,7 +100,7 @@ def main():
               c2[0]["roofline"]["algorithmic_bytes_per_launch"], c2[0]["roofline"]["avg_launch_ms"])
     q4f = pick("q4_fetch", "scan2_iupac_kernel")
     if q4f:
-        total_kb = q4f["FETCH_SIZE"]["sum"] / 4.0        # the pass runs four steps (set-up, one warm-up, two timed), each reading the whole database once
+        total_kb = q4f["FETCH_SIZE"]["sum"] / 6.0        # the pass runs six steps (set-up, one warm-up, two timed, two search-only), each reading the whole database once
         out["q4_1Mrefs_check"] = {"kernel": "scan2_iupac_kernel", "fetch_bytes_corrected_per_step": total_kb * 1024 * 2, "packed_bytes_per_step": 1000000 * 14976,
                                   "ratio": total_kb * 1024 * 2 / (1000000 * 14976.0)}
     json.dump(out, open(os.path.join(P, "%s_pmc_traffic.json" % R), "w"), indent=1)

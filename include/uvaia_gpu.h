@@ -83,10 +83,12 @@ typedef struct {
                                   references that go on to the queries, 2 = by the consensus pass itself, for every reference (default 2) */
   int query_tables;            /* the scans' query-side tables (plane words, column classes, rare columns, compressed planes, item streams) are built
                                   1 = by host threads, 2 = on the device from the raw rows (default 2); same bytes either way */
-  int replay_extras;           /* packed-plane scan, default mode: 2 = the scan also leaves text - ACGT and partial - text matches of every pair and the
-                                  replay admits without a memory round trip (default 2), 1 = the replay fetches them per admitted pair */
+  int replay_extras;           /* default mode: 0 = the library's choice (as 2 over the packed-plane scan, i.e. up to 32 queries; as 1 above), 2 = the scan also
+                                  leaves text - ACGT and partial - text matches of every pair and the replay admits without a memory round trip (up to 128
+                                  queries; over the column-compressed scan two kernels after the scan make them), 1 = the replay fetches them per admitted pair */
   int replay_cus;              /* compute units set aside for the replay's stream, the scans and the rebuild getting the others (CU masks): 0 = the
-                                  library's choice (8, one per XCD, where replay_extras applies; none otherwise), -1 = none, n > 0 = n */
+                                  library's choice (where replay_extras applies as many as hold one replay block per query at once, 8 up to 32 queries;
+                                  none otherwise), -1 = none, n > 0 = n; 1000 * t + n also sets the replay's staging depth to t = 32, 16 or 8 tiles */
   int scan_streams;            /* resident search: consecutive slices' scans alternate over 1..3 streams (0 = the library's choice by launch size);
                                   100 + p (p = 1..98): a pool's first slice is p % of an equal share (default 70), 199: equal slices */
   int pipeline;                /* resident search over the column-compressed scan: 2 = a slice's replay runs next to its scan and follows its progress counters

@@ -38,7 +38,7 @@ def main():
               ("emu_refshard_8.json", "emulated_reference_shards_8.json"), ("emu_refshard_8_config3.json", "emulated_reference_shards_8_config3_regime.json"),
               ("load_latency.txt", "load_latency_next_to_a_stream.txt"), ("probe_q4.txt", "small_query_replay_tiles_opened.txt"),
               ("probe_q4_timing.txt", "small_query_replay_time_split.txt"), ("probe_c1_timing.txt", "config1_replay_time_split.txt")]
-    for d in ("c1_fetch", "c1_write", "c1_insts_a", "c1_waits", "c1_units", "c1_tcc", "c2_fetch", "c2_write", "c2_insts_a", "c2_waits", "c2_tcc", "q4_fetch"):
+    for d in ("c1_fetch", "c1_write", "c1_insts_a", "c1_waits", "c1_units", "c1_tcc", "c2_fetch", "c2_write", "c2_insts_a", "c2_waits", "c2_tcc", "q4_fetch", "q16_insts", "q16_waits"):
         copies.append(("pmc_%s/**/*counter_collection.csv" % d, "pmc_%s_counter_collection.csv" % d))
     for src, dst in copies:
         f = first(src)
@@ -103,6 +103,18 @@ def main():
         total_kb = q4f["FETCH_SIZE"]["sum"] / 6.0        # the pass runs six steps (set-up, one warm-up, two timed, two search-only), each reading the whole database once
         out["q4_1Mrefs_check"] = {"kernel": "scan2_iupac_kernel", "fetch_bytes_corrected_per_step": total_kb * 1024 * 2, "packed_bytes_per_step": 1000000 * 14976,
                                   "ratio": total_kb * 1024 * 2 / (1000000 * 14976.0)}
+    q16i, q16w = pick("q16_insts", "scan2_iupac_kernel"), pick("q16_waits", "scan2_iupac_kernel")
+    if q16i and q16w:
+        waves_per_step = 15625 * 4                       # one block of four waves per tile of 64 references, one query tile
+        n_steps = q16i["SQ_WAVES"]["sum"] / waves_per_step
+        valu = q16i["SQ_INSTS_VALU"]["sum"] / n_steps
+        out["q16_1Mrefs_scan"] = {"kernel": "scan2_iupac_kernel<16>", "steps_in_pass": round(n_steps, 2), "valu_wave_instructions_per_step": round(valu),
+                                  "salu_per_step": round(q16i["SQ_INSTS_SALU"]["sum"] / n_steps), "smem_per_step": round(q16i["SQ_INSTS_SMEM"]["sum"] / n_steps),
+                                  "valu_pipe_ms_per_step": round(valu * 4 / (1024 * 2.4e9) * 1e3, 3),
+                                  "note": "a wave64 vector instruction occupies its SIMD16 for four cycles: 1 024 SIMDs at 2.4 GHz; the launches of a step take 3.8 ms (profiles/%s_q16_1Mrefs_kernel_stats.csv)" % R,
+                                  "of_wave_cycles": {"waiting_at_any_counter": round(q16w["SQ_WAIT_ANY"]["sum"] / q16w["SQ_WAVE_CYCLES"]["sum"], 3),
+                                                     "waiting_for_an_issue_slot": round(q16w["SQ_WAIT_INST_ANY"]["sum"] / q16w["SQ_WAVE_CYCLES"]["sum"], 3),
+                                                     "issuing_valu": round(q16w["SQ_ACTIVE_INST_VALU"]["sum"] / q16w["SQ_WAVE_CYCLES"]["sum"], 3)}}
     json.dump(out, open(os.path.join(P, "%s_pmc_traffic.json" % R), "w"), indent=1)
     print("profiles updated:", len(out["entries"]), "PMC entries")
 

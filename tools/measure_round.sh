@@ -33,8 +33,11 @@ pmc c2_insts_a "$C2" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_I
 pmc c2_waits "$C2" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
 pmc c2_tcc "$C2" TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pmc q4_fetch "python bench.py --queries 4 --refs 1000000 --pool 1000000 --steps 2 --warmup 1 --no-sweep --cpu-refs 0 --no-parity --align-queries 0" FETCH_SIZE
+Q16="python bench.py --queries 16 --refs 1000000 --pool 1000000 --steps 2 --warmup 1 --no-sweep --cpu-refs 0 --no-parity --align-queries 0"
+pmc q16_insts "$Q16" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES
+pmc q16_waits "$Q16" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
 step ball profile;   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/ball -o ball --output-format csv -- python bench.py --ball-only --steps 3 > $O/ball.json 2> $O/ball.err || exit 1
-python tools/pmc_summary.py $(for d in c1_fetch c1_write c1_insts_a c1_waits c1_units c1_tcc c2_fetch c2_write c2_insts_a c2_waits c2_tcc q4_fetch; do echo $d=$(ls $O/pmc_$d/*counter_collection.csv | head -1); done) > $O/pmc_summary.json || exit 1
+python tools/pmc_summary.py $(for d in c1_fetch c1_write c1_insts_a c1_waits c1_units c1_tcc c2_fetch c2_write c2_insts_a c2_waits c2_tcc q4_fetch q16_insts q16_waits; do echo $d=$(ls $O/pmc_$d/*counter_collection.csv | head -1); done) > $O/pmc_summary.json || exit 1
 fi
 if [[ $PART == *b* ]]; then
 step acgt config1;   timeout -k 10 300 python bench.py --mode acgt --steps 10 --warmup 2 --no-sweep --cpu-refs 2048 --align-queries 0 > $O/bench_acgt_c1.json 2> $O/bench_acgt_c1.err || exit 1

@@ -19,3 +19,8 @@ run q16 --queries 16 --refs 1000000 --pool 1000000 || exit 1
 run q64 --queries 64 --refs 1000000 --pool 1000000 --steps 5 || exit 1
 run c1_b || exit 1
 run c1_acgt --mode acgt || exit 1
+if [ "$2" = more ]; then
+run q8 --queries 8 --refs 1000000 --pool 1000000 || exit 1
+run q32 --queries 32 --refs 1000000 --pool 1000000 || exit 1
+run c2 --queries 10000 --refs 100000 --mode acgt --pool 65536 --steps 3 --warmup 1 || exit 1
+fi

@@ -7,8 +7,8 @@ python - $O <<'P'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-ks = [r for r in rows if any(x in r["Kernel_Name"] for x in ("scan2", "scan3", "replay", "derive_all"))]
+ks = [r for r in rows if any(x in r["Kernel_Name"] for x in ("scan2", "scan3", "replay", "derive_all", "pair_extras", "tile_bounds"))]
 t0 = int(ks[0]["Start_Timestamp"])
-for r in ks[-24:]:
+for r in ks[-40:]:
     print("%-28s start %9.1f us  dur %8.1f us  stream %s" % (r["Kernel_Name"][5:33], (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Stream_Id"]))
 P

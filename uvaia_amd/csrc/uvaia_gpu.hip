@@ -108,7 +108,7 @@ struct uvaia_gpu_ctx {
   uint32_t *d_extb[NBUF] = {};            // packed-plane scan, default mode: per pair the other two counters (scan2_extras), one per counter buffer; sized like it
   uint32_t *d_rtpb[NBUF] = {};            // ... and per reference the consensus pre-score packed into one dword (query sets with constant-and-complete columns)
   uint4 *d_tb8[NBUF] = {};                // ... and per (query, tile of 64) the eight-entry bounds replay3_kernel walks (tile_bounds8)
-  bool use_ext = false;                   // the packed-plane scan leaves the extras and replay3_kernel runs (default mode, up to two query tiles)
+  bool use_ext = false;                   // the scan leaves the extras and replay3_kernel runs (default mode: packed-plane scan, or the column-compressed one up to 128 queries)
   int4 *d_rtb[NBUF] = {};                 // per reference of a slice: untruncated consensus pre-score (query sets with constant-and-complete columns), one per counter buffer
   int slice_tiles[NBUF] = {}, slice_rb[NBUF] = {}, slice_re[NBUF] = {};
   long long slice_tf[NBUF] = {};
@@ -144,6 +144,7 @@ struct uvaia_gpu_ctx {
   int replay_lq = -1;            // replay caches the query's planes in LDS (22 KB per block): -1 = only with few queries (see open)
   int replay_prio = 1;           // replay waves raise their issue priority
   bool head_full = false;        // tuning.head_scan = 2: the stream's first two tiles go through the four-counter scan (heaps fill without on-demand fetches; measured slower)
+  int replay_half = 32;          // tiles per staging buffer of replay3_kernel (32, 16 or 8: its LDS decides how many of its blocks share a compute unit)
   int replay_cus = 0;            // compute units set aside for the replay kernels of the resident search (0: none, the streams share the chip by priority)
   hipStream_t rep_stream = nullptr; hipEvent_t rep_ev[2] = {};   // ... the stream masked to them, and the events that splice its kernels into `stream`'s order
   int scan_R = 2;                // reference tiles per wave of scan3_kernel (the item stream is built for it)

@@ -50,7 +50,6 @@ def files(tmp_path_factory, bundled_db):
 
 @pytest.mark.parametrize("extra,kw", [
     ([], {}),
-    (["--acgt"], {"acgt": True}),
     (["--trim", "230", "-x"], {"trim": 230, "exclude_self": True}),
     (["-k", "-n", "1"], {"keep_resolved": True, "nbest": 1}),
     (["--devices", "0,0"], {}),                                                        # two contexts on one GPU: reference shards from the C host

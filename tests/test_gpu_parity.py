@@ -384,7 +384,7 @@ def test_truncated_consensus_prescore_is_reproduced():
 def test_random_small_many_states(acgt):
     """Many tiny problems with heavy ties and tiny heaps: exercises heap layout / tie handling / T dynamics."""
     rng = np.random.default_rng(5)
-    for it in range(6):
+    for it in range(5):
         L = int(rng.integers(40, 200))
         refs, root, cols = F.synth_alignment(int(rng.integers(5, 150)), L, seed=100 + it, p_snp=0.02, p_amb=0.01)
         qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=200 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)
@@ -553,7 +553,7 @@ def test_resident_search_of_few_queries_many_states(acgt):
     reproduce the oracle on many tiny problems with heavy ties, tiny heaps and tiny pools (snapshots taken often: the cut pre-scores
     of src/nearest.c:431-432)."""
     rng = np.random.default_rng(17)
-    for it in range(5):
+    for it in range(4):
         L = int(rng.integers(40, 260))
         refs, root, cols = F.synth_alignment(int(rng.integers(5, 400)), L, seed=300 + it, p_snp=0.02, p_amb=0.01)
         qs, _, _ = F.synth_alignment(int(rng.integers(1, 9)), L, seed=400 + it, root=root, poly_cols=cols, p_snp=0.02, p_amb=0.01)

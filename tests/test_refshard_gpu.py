@@ -99,7 +99,7 @@ def test_tolerance_range_may_start_anywhere_under_reference_shards(data):
 
 
 @pytest.mark.parametrize("flags", [["--queries", "200", "--refs", "8192", "--nbest", "20"],
-                                   ["--queries", "2500", "--refs", "2304", "--mode", "acgt"]])       # config[3]'s regime per rank: 1 250 queries replayed by each of the two ranks (not a multiple of 64), --acgt, k = 100
+                                   ["--queries", "2500", "--refs", "1536", "--mode", "acgt"]])       # config[3]'s regime per rank: 1 250 queries replayed by each of the two ranks (not a multiple of 64), --acgt, k = 100
 def test_bench_two_ranks_over_gloo_on_one_card_end_to_end(flags):
     """`bench.py --gpus 2` as the driver launches it for N > 1 (it starts its own ranks when no launcher did), rehearsed on one card
     with the exchange over gloo (UVAIA_BENCH_BACKEND): the JSON line must be a two-rank line and the sample that went through the

@@ -266,9 +266,9 @@ def test_full_size_config2_three_ways_agree_and_scores_are_the_oracles():
     overlapping the sub-slice scans) leaves every heap full, what is kept was dumped, and the six scores of heap entries are the
     oracle's untruncated pair scores (every entry that refers to one of 160 sampled references).  The three ways of running a
     search -- the timed step, the same step with every launch serialised, the streaming push path -- are compared on the first
-    150 000 references of the same stream (heaps, tolerances, dump flags identical): three pools, sub-slices that wrap the ring of
-    counter buffers, a sixth of the generating and loading (the suite's budget)."""
-    n_ref, n_three, pool, nq = 1000000, 150000, 65536, 10000
+    132 000 references of the same stream (heaps, tolerances, dump flags identical): three pools, sub-slices that wrap the ring of
+    counter buffers, a seventh of the generating and loading (the suite's budget)."""
+    n_ref, n_three, pool, nq = 1000000, 132000, 65536, 10000
     gen = hostlib.Synth(29903, seed=20241008, preset=0)
     qs, _ = gen.generate_bytes(QUERY_INDEX0, nq)
     qn = _names(nq, "query_")

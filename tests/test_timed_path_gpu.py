@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import timed_path_workloads as W
 from uvaia_amd import capi, hostlib
 
 pytestmark = pytest.mark.gpu
@@ -46,14 +47,10 @@ def _timed_step(eng, pool):
 
 @pytest.fixture(scope="module")
 def config1_sample():
-    """1 000 generator queries x 8 000 generator references x 29 903 columns, k = 100, one pool (pool 65 536 > 8 000)."""
-    gen = hostlib.Synth(29903, seed=20241008, preset=0)
-    qs, _ = gen.generate_bytes(QUERY_INDEX0, 1000)
-    qn = _names(1000, "query_")
-    refs, _ = gen.generate_bytes(0, 8000)
-    oq = O.Query(qs, qn)
-    gold = O.search(oq, refs, _names(len(refs)), pool=8000, nbest=100, ambig_r=0.5)
-    return gen, qs, qn, refs, oq, gold
+    """1 000 generator queries x 8 000 generator references x 29 903 columns, k = 100, one pool (pool 65 536 > 8 000); the oracle's
+    answer is compared through its committed digest (tests/timed_path_workloads.py: the oracle itself runs only to explain a difference)."""
+    w = W.Workload("config1_sample")
+    return w.gen, w.qs, w.qn, w.refs, w, w
 
 
 def test_config1_regime_default_switches_equal_oracle(config1_sample):
@@ -67,9 +64,7 @@ def test_config1_regime_default_switches_equal_oracle(config1_sample):
         _load(eng, gen, 0, len(refs))
         for _ in range(2):                                   # a second step over the same resident database gives the same answer
             rows, T, ent = _timed_step(eng, 8000)
-            assert rows == _want(gold, oq.ntax)
-            assert T == gold.final_T
-            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+            gold.check(rows, T, np.nonzero(ent)[0])
         admitted, demanded, dense = eng.replay_stats(reset=True)
         assert admitted > 100 * 1000                         # heaps fill and keep turning over: the regime of the benchmark
 
@@ -82,8 +77,7 @@ def test_config1_regime_sub_slices_equal_oracle(config1_sample):
     with pq.open_engine(nbest=100, max_pool=8000, tuning={"subslice_refs": 1700}) as eng:
         _load(eng, gen, 0, len(refs))
         rows, T, ent = _timed_step(eng, 8000)
-        assert rows == _want(gold, oq.ntax) and T == gold.final_T
-        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+        gold.check(rows, T, np.nonzero(ent)[0])
 
 
 def test_config1_regime_pipelined_replay_equals_oracle(config1_sample):
@@ -96,8 +90,7 @@ def test_config1_regime_pipelined_replay_equals_oracle(config1_sample):
         _load(eng, gen, 0, len(refs))
         for _ in range(2):
             rows, T, ent = _timed_step(eng, 65536)
-            assert rows == _want(gold, oq.ntax) and T == gold.final_T
-            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+            gold.check(rows, T, np.nonzero(ent)[0])
 
 
 def test_config1_regime_streaming_push_equals_oracle(config1_sample):
@@ -107,8 +100,7 @@ def test_config1_regime_streaming_push_equals_oracle(config1_sample):
     with pq.open_engine(nbest=100, max_pool=8000) as eng:
         ent = eng.push(refs)
         n, T, sc, od = eng.drain()
-        assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
-        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+        gold.check(capi.finalise_heaps(n, sc, od), T, np.nonzero(ent)[0])
 
 
 def test_group_of_four_contexts_at_benchmark_shape(config1_sample):
@@ -124,8 +116,7 @@ def test_group_of_four_contexts_at_benchmark_shape(config1_sample):
         g.db_rederive()
         ent = g.search_resident(8000)
         n, T, sc, od = g.drain()
-    assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
-    assert list(np.nonzero(ent)[0]) == list(gold.saved)
+    gold.check(capi.finalise_heaps(n, sc, od), T, np.nonzero(ent)[0])
 
 
 def test_config2_regime_acgt_many_query_tiles_equal_oracle():
@@ -149,14 +140,9 @@ def test_config2_regime_acgt_many_query_tiles_equal_oracle():
 
 @pytest.fixture(scope="module")
 def config2_sample():
-    """10 000 generator queries x 1 536 generator references x 29 903 columns, --acgt, k = 100, one pool, and the oracle's answer."""
-    gen = hostlib.Synth(29903, seed=20241008, preset=0)
-    qs, _ = gen.generate_bytes(QUERY_INDEX0, 10000)
-    qn = _names(10000, "query_")
-    refs, _ = gen.generate_bytes(0, 1536)
-    oq = O.Query(qs, qn, acgt=True)
-    gold = O.search(oq, refs, _names(len(refs)), pool=1536, nbest=100, ambig_r=0.5)
-    return gen, qs, qn, refs, oq, gold
+    """10 000 generator queries x 1 536 generator references x 29 903 columns, --acgt, k = 100, one pool; the oracle's answer as above."""
+    w = W.Workload("config2_sample")
+    return w.gen, w.qs, w.qn, w.refs, w, w
 
 
 def test_group_of_eight_contexts_at_config3_shape(config2_sample):
@@ -177,8 +163,7 @@ def test_group_of_eight_contexts_at_config3_shape(config2_sample):
         g.db_rederive()
         ent = g.search_resident(n_ref)
         n, T, sc, od = g.drain()
-    assert capi.finalise_heaps(n, sc, od) == _want(gold, oq.ntax) and list(T) == gold.final_T
-    assert list(np.nonzero(ent)[0]) == list(gold.saved)
+    gold.check(capi.finalise_heaps(n, sc, od), T, np.nonzero(ent)[0])
 
 
 def test_config2_regime_10000_queries_acgt_equal_oracle(config2_sample):
@@ -193,14 +178,12 @@ def test_config2_regime_10000_queries_acgt_equal_oracle(config2_sample):
         _load(eng, gen, 0, len(refs))
         for _ in range(2):
             rows, T, ent = _timed_step(eng, 1536)
-            assert rows == _want(gold, oq.ntax) and T == gold.final_T
-            assert list(np.nonzero(ent)[0]) == list(gold.saved)
+            gold.check(rows, T, np.nonzero(ent)[0])
     # the same queries, sub-slices that are not tile aligned and wrap the ring of counter buffers
     with pq.open_engine(nbest=100, max_pool=1536, tuning={"subslice_refs": 500}) as eng:
         _load(eng, gen, 0, len(refs))
         rows, T, ent = _timed_step(eng, 1536)
-        assert rows == _want(gold, oq.ntax) and T == gold.final_T
-        assert list(np.nonzero(ent)[0]) == list(gold.saved)
+        gold.check(rows, T, np.nonzero(ent)[0])
 
 
 def _heap_pairs(rows):

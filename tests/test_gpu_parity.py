@@ -673,3 +673,17 @@ def test_scan_side_extras_equal_the_on_demand_counters(nq, trim):
                 assert demanded >= admitted > 0
         rows, T, ent = _resident_search(q, refs, 130, 7, tuning=tuning)
         assert rows == want and T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved), extras
+
+
+@pytest.mark.parametrize("nbest,n_ref", [(3000, 3400), (4500, 4700)])
+def test_large_heaps_with_a_handful_of_queries(nbest, n_ref):
+    """Three queries in default mode with heaps of thousands of entries: the replay over the scan-side extras shrinks its staging buffers to
+    make room for the heap in LDS (3 000 entries) or gives way to the on-demand replay (4 500 entries: nothing fits next to 144 KB of
+    heap); either way the heaps fill, turn over, and equal the oracle's (heaps above 127 entries also take the level-by-level update)."""
+    L = 300
+    refs, root, cols = F.synth_alignment(n_ref, L, seed=71, p_snp=0.01, p_amb=0.002)
+    qs = F.synth_alignment(3, L, seed=72, root=root, poly_cols=cols, p_snp=0.01, p_amb=0.002)[0]
+    q = O.Query(qs, _names(3, "q"), ambig_q=1.0)
+    gold = O.search(q, refs, _names(len(refs)), pool=1500, nbest=nbest, ambig_r=1.0)
+    rows, T, ent = _resident_search(q, refs, 1500, nbest)
+    assert rows == [[(tuple(s_), o) for o, _, s_ in r] for r in gold.rows] and T == gold.final_T and list(np.nonzero(ent)[0]) == list(gold.saved)
